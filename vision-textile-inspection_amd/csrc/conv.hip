@@ -1,0 +1,279 @@
+// Implicit-GEMM convolution for gfx950 (MI355X): NHWC activations, MFMA 16x16x32 f16 (or the
+// exact-f32 16x16x4 form), fp32 accumulate, fused bias + SiLU (+ residual) epilogue.
+//
+// Implements the Conv-BN-SiLU / Conv2d / ConvTranspose2d(2,2) rows of the YOLOv8-seg table
+//  that run behind the reference's model.predict()
+// (measurement.py:208-210).
+//
+// Mapping to the hardware
+//  * GEMM view: M = output pixels of one TH x TW tile of one frame, N = output channels,
+//    K = taps x input channels, walked in chunks of KC = 32 (fp16) / 16 (fp32) channels.
+//  * The MFMA "A" operand (rows) carries the WEIGHTS and the "B" operand (cols) the PIXELS, so an
+//    accumulator lane ends up with 4 consecutive output channels of one pixel: the epilogue
+//    stores 8 B (fp16) / 16 B (fp32) per lane straight into the NHWC tensor, no LDS transpose.
+//  * Input patch (tile + halo) is staged once per chunk into LDS as 4 planes of [pixel][16 B]
+//    (plane q = channels q*VEC..q*VEC+VEC-1 of the chunk): the lane->(pixel = lane&15,
+//    k-group = lane>>4) operand map then reads 16 consecutive 16-B slots per k-group --
+//    conflict-free ds_read_b128 -- and every tap is a constant byte offset.
+//  * Weights are pre-packed on the host in fragment order (weights.cpp) and staged per chunk as a
+//    straight 1-KiB-per-fragment copy.
+//  * 256 threads = 4 waves; WN of them split N, 4/WN split M; each wave owns a 5 x NREP grid of
+//    16x16 accumulators (80 pixels x 16*NREP channels).
+#include "vti_internal.h"
+
+namespace vti {
+
+typedef _Float16 half_t;
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <typename T> struct Tr;
+template <> struct Tr<half_t> { typedef half8 vec; static constexpr int VEC = 8, KC = 32; };
+template <> struct Tr<float> { typedef f32x4 vec; static constexpr int VEC = 4, KC = 16; };
+
+__device__ __forceinline__ f32x4 mma(half8 w, half8 x, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(w, x, c, 0, 0, 0);
+}
+// f32: lane l feeds k = 4*(l>>4)+i to the i-th 16x16x4 step on both operands, so the k order is
+// a permutation shared by weights and pixels (exact f32 FMA chain either way).
+__device__ __forceinline__ f32x4 mma(f32x4 w, f32x4 x, f32x4 c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(w[0], x[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(w[1], x[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(w[2], x[2], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(w[3], x[3], c, 0, 0, 0);
+    return c;
+}
+
+__device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }
+
+constexpr int MREP = 5;
+
+__host__ __device__ inline int patch_dim(int t, int ks, int s, int mode) { return mode == 1 ? t : (t - 1) * s + ks; }
+
+size_t conv_lds_bytes(int ks, int stride, int mode, int TH, int TW, int WN, int NREP) {
+    const int npix = patch_dim(TH, ks, stride, mode) * patch_dim(TW, ks, stride, mode);
+    const size_t plane = (size_t)((npix + 15) & ~15) * 16;
+    const int taps = mode == 1 ? 1 : ks * ks;
+    return 4 * plane + (size_t)WN * NREP * taps * 1024;
+}
+
+template <typename T, int KS, int S, int NREP, int MODE>
+__global__ __launch_bounds__(256) void conv_kernel(const ConvParams p) {
+    using vec = typename Tr<T>::vec;
+    constexpr int VEC = Tr<T>::VEC, KC = Tr<T>::KC;
+    constexpr int TAPS = (MODE == 1) ? 1 : KS * KS;
+    constexpr int PAD = KS / 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int WN = p.WN;
+    const int wn = wave % WN, wm = wave / WN;
+    int t = blockIdx.x;
+    const int tx = t % p.tiles_x; t /= p.tiles_x;
+    const int ty = t % p.tiles_y;
+    const int b = t / p.tiles_y;
+    const int oy0 = ty * p.TH, ox0 = tx * p.TW;
+    const int PH = patch_dim(p.TH, KS, S, MODE), PW = patch_dim(p.TW, KS, S, MODE);
+    const int npix = PH * PW;
+    const int plane_bytes = ((npix + 15) & ~15) * 16;
+    char* smA = smem;
+    char* smB = smem + 4 * plane_bytes;
+    const int NTB = WN * NREP;
+    const int nt0 = blockIdx.y * NTB;
+    const int tile_px = p.TH * p.TW;
+
+    // per-lane pixel bookkeeping for the MREP pixel tiles of this wave
+    int abase[MREP], opy[MREP], opx[MREP];
+    bool pvalid[MREP];
+#pragma unroll
+    for (int m = 0; m < MREP; ++m) {
+        const int pp = (wm * MREP + m) * 16 + (lane & 15);
+        const bool v = pp < tile_px;
+        const int pc = v ? pp : 0;
+        const int py = pc / p.TW, px = pc - py * p.TW;
+        opy[m] = oy0 + py; opx[m] = ox0 + px;
+        pvalid[m] = v && opy[m] < p.Hout && opx[m] < p.Wout;
+        const int lpix = (MODE == 1) ? pc : (py * S) * PW + px * S;
+        abase[m] = (lane >> 4) * plane_bytes + lpix * 16;
+    }
+
+    f32x4 acc[MREP][NREP];
+#pragma unroll
+    for (int m = 0; m < MREP; ++m)
+#pragma unroll
+        for (int n = 0; n < NREP; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int iy0 = oy0 * S - PAD, ix0 = ox0 * S - PAD;
+
+    for (int c = 0; c < p.nchunks; ++c) {
+        if (c) __syncthreads();
+        // ---- stage the input patch: plane q <- channels [c*KC + q*VEC, +VEC) of every patch pixel
+        if constexpr (MODE == 0) {
+            const T* inb = (const T*)p.in;
+            for (int i = tid; i < npix * 4; i += 256) {
+                const int pix = i >> 2, q = i & 3;
+                const int py = pix / PW, px = pix - py * PW;
+                const int y = iy0 + py, x = ix0 + px;
+                const int ch = c * KC + q * VEC;
+                vec v;
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) v[j] = 0;
+                if ((unsigned)y < (unsigned)p.Hin && (unsigned)x < (unsigned)p.Win && ch < p.Cin)
+                    v = *(const vec*)(inb + ((size_t)(b * p.Hin + y) * p.Win + x) * p.in_ld + p.in_coff + ch);
+                *(vec*)(smA + q * plane_bytes + pix * 16) = v;
+            }
+        } else {
+            // conv0: u8 HWC3 frame, im2col on the fly: k = (kh*3+kw)*3 + channel, K = 27 padded to 32
+            const uint8_t* inb = (const uint8_t*)p.in;
+            for (int i = tid; i < npix * 4; i += 256) {
+                const int pix = i >> 2, q = i & 3;
+                const int py = pix / PW, px = pix - py * PW;
+                const int oy = oy0 + py, ox = ox0 + px;
+                vec v;
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    const int k = c * KC + q * VEC + j;
+                    float f = 0.f;
+                    if (k < 27) {
+                        const int tap = k / 3, chn = k - tap * 3;
+                        const int kh = tap / 3, kw = tap - kh * 3;
+                        const int y = oy * 2 - 1 + kh, x = ox * 2 - 1 + kw;
+                        if ((unsigned)y < (unsigned)p.Hin && (unsigned)x < (unsigned)p.Win) {
+                            const int cs = p.swap_rb ? 2 - chn : chn;
+                            f = (float)inb[((size_t)(b * p.Hin + y) * p.Win + x) * 3 + cs] / 255.0f;
+                        }
+                    }
+                    v[j] = (T)f;
+                }
+                *(vec*)(smA + q * plane_bytes + pix * 16) = v;
+            }
+        }
+        // ---- stage this chunk's weight fragments (contiguous in the packed image)
+        {
+            const vec* wsrc = (const vec*)p.wpk + ((size_t)c * p.ntiles_n + nt0) * (TAPS * 64);
+            int ntv = p.ntiles_n - nt0;
+            ntv = ntv < NTB ? ntv : NTB;
+            const int nvalid = ntv * TAPS * 64;
+            for (int i = tid; i < NTB * TAPS * 64; i += 256) {
+                vec v;
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) v[j] = 0;
+                if (i < nvalid) v = wsrc[i];
+                ((vec*)smB)[i] = v;
+            }
+        }
+        __syncthreads();
+        // ---- MFMA over the taps of this chunk
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const int toff = (MODE == 1) ? 0 : ((tap / KS) * PW + (tap % KS)) * 16;
+            vec w[NREP];
+#pragma unroll
+            for (int n = 0; n < NREP; ++n)
+                w[n] = *(const vec*)(smB + ((size_t)((wn * NREP + n) * TAPS + tap) * 64 + lane) * 16);
+#pragma unroll
+            for (int m = 0; m < MREP; ++m) {
+                const vec x = *(const vec*)(smA + abase[m] + toff);
+#pragma unroll
+                for (int n = 0; n < NREP; ++n) acc[m][n] = mma(w[n], x, acc[m][n]);
+            }
+        }
+    }
+
+    // ---- epilogue: bias, SiLU, residual, store 4 consecutive channels per lane
+#pragma unroll
+    for (int m = 0; m < MREP; ++m) {
+        if (!pvalid[m]) continue;
+#pragma unroll
+        for (int n = 0; n < NREP; ++n) {
+            const int cout0 = (nt0 + wn * NREP + n) * 16 + (lane >> 4) * 4;
+            if (cout0 >= p.Cout) continue;
+            f32x4 v = acc[m][n];
+            const f32x4 bb = *(const f32x4*)(p.bias + cout0);   // bias is padded to 16 floats per n-tile
+            v += bb;
+            if (p.act) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = silu(v[j]);
+            }
+            size_t opix;
+            int co = cout0;
+            if (p.deconv_c) {
+                const int q = cout0 / p.deconv_c;
+                co = cout0 - q * p.deconv_c;
+                opix = ((size_t)(b * 2 * p.Hout + 2 * opy[m] + (q >> 1))) * (2 * p.Wout) + 2 * opx[m] + (q & 1);
+            } else {
+                opix = ((size_t)(b * p.Hout + opy[m])) * p.Wout + opx[m];
+            }
+            if (p.has_res) {
+                const T* rp = (const T*)p.res + opix * p.res_ld + p.res_coff + co;
+                if constexpr (sizeof(T) == 2) {
+                    const half4 r = *(const half4*)rp;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] += (float)r[j];
+                } else {
+                    v += *(const f32x4*)rp;
+                }
+            }
+            const size_t o = opix * p.out_ld + p.out_coff + co;
+            if (p.scalar_store) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (cout0 + j < p.Cout) {
+                        if (p.out_f32) ((float*)p.out)[o + j] = v[j];
+                        else ((T*)p.out)[o + j] = (T)v[j];
+                    }
+                }
+            } else if (p.out_f32 || sizeof(T) == 4) {
+                *(f32x4*)((float*)p.out + o) = v;
+            } else {
+                half4 hv;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) hv[j] = (half_t)v[j];
+                *(half4*)((half_t*)p.out + o) = hv;
+            }
+        }
+    }
+}
+
+template <typename T, int KS, int S, int MODE>
+static hipError_t launch_nrep(int nrep, const ConvParams& p, dim3 grid, size_t lds, hipStream_t st) {
+#define VTI_LAUNCH(N)                                                                         \
+    case N: {                                                                                 \
+        auto k = conv_kernel<T, KS, S, N, MODE>;                                              \
+        if (lds > 64 * 1024) {                                                                \
+            hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            if (e != hipSuccess) return e;                                                    \
+        }                                                                                     \
+        hipLaunchKernelGGL(k, grid, dim3(256), lds, st, p);                                   \
+        return hipGetLastError();                                                             \
+    }
+    switch (nrep) {
+        VTI_LAUNCH(1) VTI_LAUNCH(2) VTI_LAUNCH(3) VTI_LAUNCH(4) VTI_LAUNCH(5)
+        default: return hipErrorInvalidValue;
+    }
+#undef VTI_LAUNCH
+}
+
+template <typename T>
+static hipError_t launch_t(int ks, int stride, int nrep, int mode, const ConvParams& p, dim3 grid, size_t lds,
+                           hipStream_t st) {
+    if (mode == 1) return launch_nrep<T, 3, 2, 1>(nrep, p, grid, lds, st);
+    if (ks == 1 && stride == 1) return launch_nrep<T, 1, 1, 0>(nrep, p, grid, lds, st);
+    if (ks == 3 && stride == 1) return launch_nrep<T, 3, 1, 0>(nrep, p, grid, lds, st);
+    if (ks == 3 && stride == 2) return launch_nrep<T, 3, 2, 0>(nrep, p, grid, lds, st);
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_conv(int dtype, int ks, int stride, int nrep, int mode, const ConvParams& p, size_t lds_bytes,
+                       hipStream_t st) {
+    const int NTB = p.WN * nrep;
+    dim3 grid((unsigned)(p.B * p.tiles_y * p.tiles_x), (unsigned)((p.ntiles_n + NTB - 1) / NTB));
+    if (grid.x == 0) return hipSuccess;
+    // host-side shape guard: the pixel tile must fit the 4/WN waves x 5 x 16 pixels
+    if (p.TH * p.TW > (4 / p.WN) * MREP * 16 || (p.WN != 1 && p.WN != 2 && p.WN != 4)) return hipErrorInvalidValue;
+    if (dtype == VTI_F16) return launch_t<half_t>(ks, stride, nrep, mode, p, grid, lds_bytes, st);
+    return launch_t<float>(ks, stride, nrep, mode, p, grid, lds_bytes, st);
+}
+
+}  // namespace vti

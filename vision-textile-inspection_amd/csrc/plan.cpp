@@ -1,0 +1,281 @@
+// Host-side network plan for YOLOv8-seg: the fused conv table, the concat-free NHWC buffer
+// graph and per-conv launch geometry.  Pure host code (no GPU calls) so it can be built and
+// checked on a CPU-only box.
+//
+// What it stands in for: the module list Ultralytics unpickles from the .pt behind
+// `YOLO(model_path)` (reference: measurement.py:145) -- yolov8-seg.yaml scaled by
+// depth/width/max_channels.  Concats are never
+// materialised: every producer writes straight into its consumer's channel slice.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+#include "vti_internal.h"
+
+namespace vti {
+
+namespace {
+
+struct Scale { char tag; double depth, width; int maxc; };
+const Scale kScales[] = {{'n', 0.33, 0.25, 1024}, {'s', 0.33, 0.50, 1024}, {'m', 0.67, 0.75, 768},
+                         {'l', 1.00, 1.00, 512},  {'x', 1.00, 1.25, 512}};
+
+int make_divisible(double x, int d) { return (int)std::ceil(x / d) * d; }
+// Python round(): half to even.
+int py_round(double x) { return (int)std::nearbyint(x); }
+
+struct Builder {
+    Plan& P;
+    int maxB;
+    explicit Builder(Plan& p) : P(p), maxB(p.desc.max_batch) {}
+
+    int new_buf(int C, int H, int W, int elem = EL_T) {
+        Buf b;
+        b.C = C; b.H = H; b.W = W; b.elem = elem; b.off = 0;
+        const size_t es = elem == EL_T ? (size_t)P.esize : elem == EL_F32 ? 4 : 1;
+        b.bytes = (size_t)maxB * H * W * C * es;
+        P.bufs.push_back(b);
+        return (int)P.bufs.size() - 1;
+    }
+    View whole(int buf) { View v; v.buf = buf; v.coff = 0; v.C = P.bufs[buf].C; return v; }
+    View slice(int buf, int coff, int C) { View v; v.buf = buf; v.coff = coff; v.C = C; return v; }
+
+    // Adds one row to the conv table and the op that runs it.
+    void conv(const std::string& name, View in, View out, int k, int s, int kind, bool out_f32 = false,
+              const View* res = nullptr) {
+        const Buf& ib = P.bufs[in.buf];
+        ConvRow r;
+        r.name = name; r.c1 = in.C; r.c2 = out.C; r.k = k; r.s = s; r.kind = kind;
+        r.h_in = ib.H; r.w_in = ib.W;
+        if (kind == 2) { r.h_out = 2 * ib.H; r.w_out = 2 * ib.W; }
+        else { r.h_out = (ib.H + 2 * (k / 2) - k) / s + 1; r.w_out = (ib.W + 2 * (k / 2) - k) / s + 1; }
+        P.convs.push_back(r);
+        P.conv_out.push_back(out);
+        Op op;
+        op.kind = (ib.elem == EL_U8) ? OP_CONV0 : OP_CONV;
+        op.conv = (int)P.convs.size() - 1;
+        op.in = in; op.out = out; op.out_f32 = out_f32;
+        if (res) { op.res = *res; op.has_res = true; }
+        P.ops.push_back(op);
+    }
+
+    // C2f(c1, c2, n, shortcut): cv1 -> 2c; n x Bottleneck(c, c, 3x3, 3x3) chained on the last
+    // chunk; cv2 over all (2+n)c channels.  Y holds every chunk so `cat` is free.
+    void c2f(int idx, View in, View out, int n, bool shortcut) {
+        const Buf& ib = P.bufs[in.buf];
+        const int c = out.C / 2;
+        const int Y = new_buf((2 + n) * c, ib.H, ib.W);
+        char nm[64];
+        snprintf(nm, sizeof nm, "model.%d.cv1", idx);
+        conv(nm, in, slice(Y, 0, 2 * c), 1, 1, 0);
+        for (int j = 0; j < n; ++j) {
+            const int T = new_buf(c, ib.H, ib.W);
+            View prev = slice(Y, (1 + j) * c, c);
+            snprintf(nm, sizeof nm, "model.%d.m.%d.cv1", idx, j);
+            conv(nm, prev, whole(T), 3, 1, 0);
+            snprintf(nm, sizeof nm, "model.%d.m.%d.cv2", idx, j);
+            conv(nm, whole(T), slice(Y, (2 + j) * c, c), 3, 1, 0, false, shortcut ? &prev : nullptr);
+        }
+        snprintf(nm, sizeof nm, "model.%d.cv2", idx);
+        conv(nm, whole(Y), out, 1, 1, 0);
+    }
+
+    void up2(View in, View out) {
+        Op op; op.kind = OP_UP2; op.in = in; op.out = out;
+        P.ops.push_back(op);
+    }
+};
+
+// Pick the launch geometry for one conv.  Templates fix MREP=5 (80 pixels per wave along M);
+// WN in {1,2,4} splits the 4 waves between pixels and couts; the pixel tile is TH x TW.
+void choose_cfg(const Plan& P, Op& op) {
+    const ConvRow& r = P.convs[op.conv];
+    ConvCfg& c = op.cfg;
+    const bool f16 = P.desc.dtype == VTI_F16;
+    const int KC = f16 ? 32 : 16;
+    const bool conv0 = op.kind == OP_CONV0;
+    const bool deconv = r.kind == 2;
+    c.gemm_n = deconv ? 4 * r.c2 : r.c2;
+    c.ntiles_n = (c.gemm_n + 15) / 16;
+    c.nchunks = conv0 ? (32 / KC) : (r.c1 + KC - 1) / KC;
+    const int ks = deconv ? 1 : r.k, st = deconv ? 1 : r.s;
+    const int Ho = deconv ? r.h_in : r.h_out, Wo = deconv ? r.w_in : r.w_out;
+    const int taps = conv0 ? 1 : ks * ks;
+
+    double best = -1;
+    for (int WN = 1; WN <= 4; WN *= 2) {
+        for (int NREP = 1; NREP <= 5; ++NREP) {
+            const int BN = WN * NREP;                    // n-tiles per workgroup
+            const int gy = (c.ntiles_n + BN - 1) / BN;
+            const double n_eff = (double)c.ntiles_n / (gy * BN);
+            if (n_eff < 0.74) continue;
+            const int BM = (4 / WN) * 80;
+            // best pixel tile for this BM
+            for (int TW = std::min(Wo, BM); TW >= 1; --TW) {   // widest first: ties keep row-contiguous tiles
+                const int TH = std::min(Ho, BM / TW);
+                if (TH < 1) continue;
+                const int tiles = ((Ho + TH - 1) / TH) * ((Wo + TW - 1) / TW);
+                const double m_eff = (double)Ho * Wo / ((double)tiles * BM);
+                const int PH = conv0 ? TH : (TH - 1) * st + ks, PW = conv0 ? TW : (TW - 1) * st + ks;
+                const size_t lds = conv_lds_bytes(ks, st, conv0 ? 1 : 0, TH, TW, WN, NREP);
+                if (lds > 80 * 1024) continue;
+                // score: MFMA efficiency, mild preference for compact input patches (halo re-reads),
+                // for bigger per-wave register tiles (LDS traffic per MFMA ~ 1/NREP + 1/5) and for
+                // >= 2 workgroups per CU of LDS.
+                const double halo = (double)(TH * TW * st * st) / (PH * PW);
+                const double lds_traffic = 1.0 / NREP + 1.0 / 5;
+                // contiguous bytes per tile row (coalescing of the staging loads / epilogue stores)
+                const double rowb = std::min(1.0, (double)TW * 64.0 / 1024.0);
+                double score = m_eff * n_eff * (0.6 + 0.4 * halo) * (0.8 + 0.2 * rowb) / (0.35 + lds_traffic);
+                if (lds > 64 * 1024) score *= 0.9;
+                const double wgs = (double)tiles * gy * P.desc.max_batch;
+                if (wgs < 512) score *= 0.5 + 0.5 * wgs / 512;
+                if (score > best) {
+                    best = score;
+                    c.TH = TH; c.TW = TW; c.WN = WN; c.NREP = NREP; c.lds = lds;
+                }
+            }
+        }
+    }
+    (void)taps;
+}
+
+}  // namespace
+
+std::string Plan::build(const vti_desc& d) {
+    desc = d;
+    const Scale* sc = nullptr;
+    for (const Scale& s : kScales) if (s.tag == d.scale) sc = &s;
+    if (!sc) return "unknown scale (expected one of n,s,m,l,x)";
+    if (d.nc < 1 || d.nm < 1 || d.reg_max < 1 || d.nm % 4 || d.nm > 64) return "bad nc/nm/reg_max";
+    if (d.reg_max != 16) return "only reg_max=16 is supported";
+    if (d.H < 32 || d.W < 32 || d.H % 32 || d.W % 32) return "H and W must be positive multiples of 32";
+    if (d.max_batch < 1) return "max_batch must be >= 1";
+    if (d.dtype != VTI_F16 && d.dtype != VTI_F32) return "dtype must be VTI_F16 or VTI_F32";
+    esize = d.dtype == VTI_F16 ? 2 : 4;
+
+    auto ch = [&](int c) { return make_divisible(std::min(c, sc->maxc) * sc->width, 8); };
+    auto rep = [&](int n) { return std::max(py_round(n * sc->depth), 1); };
+    const int c0 = ch(64), c1 = ch(128), c2 = ch(256), c3 = ch(512), c4 = ch(1024);
+    const int r0 = rep(3), r1 = rep(6), r2 = rep(6), r3 = rep(3), rn = rep(3);
+    const int npr = ch(256);
+    const int c_box = std::max(std::max(16, c2 / 4), 4 * d.reg_max);
+    const int c_cls = std::max(c2, std::min(d.nc, 100));
+    const int c_mc = std::max(c2 / 4, d.nm);
+    for (int c : {c0, c1, c2, c3, c4, npr, c_box, c_cls, c_mc})
+        if (c % 16) return "channel count not a multiple of 16 for this scale";
+
+    Builder b(*this);
+    const int H = d.H, W = d.W;
+    const int in_u8 = b.new_buf(3, H, W, EL_U8);         // caller's letterboxed frames (not in workspace)
+    const int B0 = b.new_buf(c0, H / 2, W / 2);
+    const int B1 = b.new_buf(c1, H / 4, W / 4);
+    const int B2 = b.new_buf(c1, H / 4, W / 4);
+    const int B3 = b.new_buf(c2, H / 8, W / 8);
+    const int CAT14 = b.new_buf(c3 + c2, H / 8, W / 8);   // [up(x12), x4]
+    const int B5 = b.new_buf(c3, H / 16, W / 16);
+    const int CAT11 = b.new_buf(c4 + c3, H / 16, W / 16); // [up(x9), x6]
+    const int B7 = b.new_buf(c4, H / 32, W / 32);
+    const int B8 = b.new_buf(c4, H / 32, W / 32);
+    const int SP = b.new_buf(2 * c4, H / 32, W / 32);     // SPPF: [cv1, p5, p9, p13]
+    const int CAT20 = b.new_buf(c3 + c4, H / 32, W / 32); // [conv19(p4), x9]
+    const int CAT17 = b.new_buf(c2 + c3, H / 16, W / 16); // [conv16(p3), x12]
+    const int P3 = b.new_buf(c2, H / 8, W / 8);
+    const int P4 = b.new_buf(c3, H / 16, W / 16);
+    const int P5 = b.new_buf(c4, H / 32, W / 32);
+
+    b.conv("model.0", b.whole(in_u8), b.whole(B0), 3, 2, 0);
+    b.conv("model.1", b.whole(B0), b.whole(B1), 3, 2, 0);
+    b.c2f(2, b.whole(B1), b.whole(B2), r0, true);
+    b.conv("model.3", b.whole(B2), b.whole(B3), 3, 2, 0);
+    const View x4 = b.slice(CAT14, c3, c2);
+    b.c2f(4, b.whole(B3), x4, r1, true);
+    b.conv("model.5", x4, b.whole(B5), 3, 2, 0);
+    const View x6 = b.slice(CAT11, c4, c3);
+    b.c2f(6, b.whole(B5), x6, r2, true);
+    b.conv("model.7", x6, b.whole(B7), 3, 2, 0);
+    b.c2f(8, b.whole(B7), b.whole(B8), r3, true);
+    // SPPF
+    const View x9 = b.slice(CAT20, c3, c4);
+    b.conv("model.9.cv1", b.whole(B8), b.slice(SP, 0, c4 / 2), 1, 1, 0);
+    { Op op; op.kind = OP_POOL; op.in = b.slice(SP, 0, c4 / 2); op.out = b.slice(SP, c4 / 2, 3 * (c4 / 2)); ops.push_back(op); }
+    b.conv("model.9.cv2", b.whole(SP), x9, 1, 1, 0);
+    // neck
+    b.up2(x9, b.slice(CAT11, 0, c4));
+    const View x12 = b.slice(CAT17, c2, c3);
+    b.c2f(12, b.whole(CAT11), x12, rn, false);
+    b.up2(x12, b.slice(CAT14, 0, c3));
+    b.c2f(15, b.whole(CAT14), b.whole(P3), rn, false);
+    b.conv("model.16", b.whole(P3), b.slice(CAT17, 0, c2), 3, 2, 0);
+    b.c2f(18, b.whole(CAT17), b.whole(P4), rn, false);
+    b.conv("model.19", b.whole(P4), b.slice(CAT20, 0, c3), 3, 2, 0);
+    b.c2f(21, b.whole(CAT20), b.whole(P5), rn, false);
+    // Segment head
+    const int feat[3] = {P3, P4, P5};
+    const int strides[3] = {8, 16, 32};
+    num_anchors = 0;
+    for (int l = 0; l < 3; ++l) {
+        const Buf fb = bufs[feat[l]];
+        Level lv; lv.C = fb.C; lv.H = fb.H; lv.W = fb.W; lv.stride = strides[l];
+        const char* towers[3] = {"cv2", "cv3", "cv4"};
+        const int cmid[3] = {c_box, c_cls, c_mc};
+        const int cout[3] = {4 * d.reg_max, d.nc, d.nm};
+        int outs[3];
+        for (int t = 0; t < 3; ++t) {
+            const int t1 = b.new_buf(cmid[t], fb.H, fb.W), t2 = b.new_buf(cmid[t], fb.H, fb.W);
+            outs[t] = b.new_buf(cout[t], fb.H, fb.W, EL_F32);
+            char nm[64];
+            snprintf(nm, sizeof nm, "model.22.%s.%d.0", towers[t], l);
+            b.conv(nm, b.whole(feat[l]), b.whole(t1), 3, 1, 0);
+            snprintf(nm, sizeof nm, "model.22.%s.%d.1", towers[t], l);
+            b.conv(nm, b.whole(t1), b.whole(t2), 3, 1, 0);
+            snprintf(nm, sizeof nm, "model.22.%s.%d.2", towers[t], l);
+            b.conv(nm, b.whole(t2), b.whole(outs[t]), 1, 1, 1, true);
+        }
+        lv.box_buf = outs[0]; lv.cls_buf = outs[1]; lv.mc_buf = outs[2];
+        levels.push_back(lv);
+        num_anchors += fb.H * fb.W;
+    }
+    {
+        const int pc1 = b.new_buf(npr, H / 8, W / 8), pup = b.new_buf(npr, H / 4, W / 4);
+        const int pc2 = b.new_buf(npr, H / 4, W / 4), pout = b.new_buf(d.nm, H / 4, W / 4);
+        b.conv("model.22.proto.cv1", b.whole(P3), b.whole(pc1), 3, 1, 0);
+        b.conv("model.22.proto.upsample", b.whole(pc1), b.whole(pup), 2, 2, 2);
+        b.conv("model.22.proto.cv2", b.whole(pup), b.whole(pc2), 3, 1, 0);
+        b.conv("model.22.proto.cv3", b.whole(pc2), b.whole(pout), 1, 1, 0);
+        proto_buf_c = pout;   // replaced by the caller's proto pointer at run time
+    }
+    { Op op; op.kind = OP_DECODE; ops.push_back(op); }
+
+    // workspace layout: plain bump allocation, 256-B aligned; buffer 0 (u8 input) and the
+    // proto output belong to the caller.
+    size_t off = 0;
+    for (size_t i = 0; i < bufs.size(); ++i) {
+        if ((int)i == in_u8 || (int)i == proto_buf_c) { bufs[i].off = 0; continue; }
+        bufs[i].off = off;
+        off += (bufs[i].bytes + 255) & ~(size_t)255;
+    }
+    ws_bytes = off;
+
+    // launch geometry + packed-weight offsets
+    macs = 0; fused_params = d.reg_max;
+    size_t woff = 0, boff = 0;
+    const int VECB = 16;   // bytes per lane per fragment
+    for (Op& op : ops) {
+        if (op.kind != OP_CONV && op.kind != OP_CONV0) continue;
+        const ConvRow& r = convs[op.conv];
+        macs += r.macs(); fused_params += r.fused_params();
+        choose_cfg(*this, op);
+        if (op.cfg.TH == 0) return "no launch configuration for conv " + r.name;
+        const int taps = (op.kind == OP_CONV0) ? 1 : (r.kind == 2 ? 1 : r.k * r.k);
+        op.cfg.wpk_off = woff;
+        op.cfg.bias_off = boff;
+        woff += (size_t)op.cfg.nchunks * op.cfg.ntiles_n * taps * 64 * VECB;
+        boff += (size_t)op.cfg.ntiles_n * 16;
+    }
+    wpk_bytes = woff; bias_floats = boff;
+    return "";
+}
+
+}  // namespace vti

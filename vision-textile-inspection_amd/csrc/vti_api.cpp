@@ -1,0 +1,327 @@
+// C ABI of libvti.so (declared in include/vti.h): context lifetime, plan execution on the
+// caller's HIP stream, error reporting.  Replaces the `ultralytics.YOLO` object the reference
+// builds at measurement.py:145 and calls at measurement.py:208-210.
+//
+// Error convention: every entry point returns a vti_status and records a message; nothing
+// throws across the boundary and nothing aborts (measurement.py:207-216 expects predict
+// failures to be survivable).
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "vti_internal.h"
+
+using namespace vti;
+
+struct vti_ctx {
+    Plan plan;
+    std::string err;
+    int device = -1;
+    void* d_wpk = nullptr;     // packed weights (device)
+    float* d_bias = nullptr;   // biases (device)
+    char* ws = nullptr;        // caller-owned workspace
+    size_t ws_bytes = 0;
+    size_t act_bytes = 0;      // activations part; NMS scratch follows
+    const void* last_input = nullptr;
+    void* last_proto = nullptr;
+};
+
+static std::string g_create_err;
+
+static int32_t fail(vti_ctx* c, int32_t code, const std::string& msg) {
+    if (c) c->err = msg; else g_create_err = msg;
+    return code;
+}
+static int32_t hip_fail(vti_ctx* c, hipError_t e, const char* what) {
+    return fail(c, VTI_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define VTI_HIP(c, call, what) do { hipError_t e_ = (call); if (e_ != hipSuccess) return hip_fail((c), e_, (what)); } while (0)
+
+extern "C" {
+
+int32_t vti_create(const vti_desc* desc, vti_ctx** out) {
+    if (!desc || !out) return fail(nullptr, VTI_ERR_ARG, "vti_create: null argument");
+    *out = nullptr;
+    vti_ctx* c = new (std::nothrow) vti_ctx();
+    if (!c) return fail(nullptr, VTI_ERR_NOMEM, "vti_create: out of host memory");
+    std::string e;
+    try { e = c->plan.build(*desc); } catch (const std::exception& ex) { e = ex.what(); }
+    if (!e.empty()) { delete c; return fail(nullptr, VTI_ERR_ARG, "vti_create: " + e); }
+    c->act_bytes = c->plan.ws_bytes;
+    *out = c;
+    return VTI_OK;
+}
+
+void vti_destroy(vti_ctx* c) {
+    if (!c) return;
+    if (c->d_wpk) (void)hipFree(c->d_wpk);
+    if (c->d_bias) (void)hipFree(c->d_bias);
+    delete c;
+}
+
+const char* vti_last_error(const vti_ctx* c) { return c ? c->err.c_str() : g_create_err.c_str(); }
+
+int32_t vti_num_convs(const vti_ctx* c) { return c ? (int32_t)c->plan.convs.size() : 0; }
+
+int32_t vti_conv_at(const vti_ctx* c, int32_t i, vti_conv_info* o) {
+    if (!c || !o || i < 0 || i >= (int32_t)c->plan.convs.size()) return VTI_ERR_ARG;
+    const ConvRow& r = c->plan.convs[i];
+    memset(o, 0, sizeof *o);
+    snprintf(o->name, sizeof o->name, "%s", r.name.c_str());
+    o->c1 = r.c1; o->c2 = r.c2; o->k = r.k; o->s = r.s; o->kind = r.kind;
+    o->h_in = r.h_in; o->w_in = r.w_in; o->h_out = r.h_out; o->w_out = r.w_out;
+    o->macs = r.macs();
+    for (const Op& op : c->plan.ops)
+        if ((op.kind == OP_CONV || op.kind == OP_CONV0) && op.conv == i) {
+            o->tile_h = op.cfg.TH; o->tile_w = op.cfg.TW; o->waves_n = op.cfg.WN; o->nrep = op.cfg.NREP;
+            o->lds_bytes = (int32_t)op.cfg.lds;
+        }
+    return VTI_OK;
+}
+
+int32_t vti_num_anchors(const vti_ctx* c) { return c ? c->plan.num_anchors : 0; }
+int64_t vti_fused_params(const vti_ctx* c) { return c ? c->plan.fused_params : 0; }
+int64_t vti_macs_per_frame(const vti_ctx* c) { return c ? c->plan.macs : 0; }
+int64_t vti_workspace_bytes(const vti_ctx* c) {
+    if (!c) return 0;
+    return (int64_t)(c->plan.ws_bytes + nms_workspace_bytes(c->plan.desc.max_batch, c->plan.num_anchors));
+}
+int32_t vti_num_launches(const vti_ctx* c) { return c ? (int32_t)c->plan.ops.size() : 0; }
+
+int32_t vti_load_weights(vti_ctx* c, const void* blob, size_t nbytes, int32_t device) {
+    if (!c) return VTI_ERR_ARG;
+    std::vector<uint8_t> wpk;
+    std::vector<float> bias;
+    std::string e;
+    try { e = pack_weights(c->plan, blob, nbytes, wpk, bias); } catch (const std::exception& ex) { e = ex.what(); }
+    if (!e.empty()) return fail(c, VTI_ERR_WEIGHTS, e);
+    VTI_HIP(c, hipSetDevice(device), "hipSetDevice");
+    if (c->d_wpk) { (void)hipFree(c->d_wpk); c->d_wpk = nullptr; }
+    if (c->d_bias) { (void)hipFree(c->d_bias); c->d_bias = nullptr; }
+    VTI_HIP(c, hipMalloc(&c->d_wpk, wpk.size()), "hipMalloc(weights)");
+    VTI_HIP(c, hipMalloc((void**)&c->d_bias, bias.size() * sizeof(float)), "hipMalloc(bias)");
+    VTI_HIP(c, hipMemcpy(c->d_wpk, wpk.data(), wpk.size(), hipMemcpyHostToDevice), "hipMemcpy(weights)");
+    VTI_HIP(c, hipMemcpy(c->d_bias, bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice), "hipMemcpy(bias)");
+    c->device = device;
+    return VTI_OK;
+}
+
+int32_t vti_set_workspace(vti_ctx* c, void* dev_ws, size_t nbytes) {
+    if (!c) return VTI_ERR_ARG;
+    if (!dev_ws || ((uintptr_t)dev_ws & 255)) return fail(c, VTI_ERR_ARG, "vti_set_workspace: pointer must be 256-B aligned");
+    if ((int64_t)nbytes < vti_workspace_bytes(c)) return fail(c, VTI_ERR_NOMEM, "vti_set_workspace: workspace too small");
+    c->ws = (char*)dev_ws;
+    c->ws_bytes = nbytes;
+    return VTI_OK;
+}
+
+static int32_t check_ready(vti_ctx* c, int32_t B, const char* fn) {
+    if (!c) return VTI_ERR_ARG;
+    if (B < 0 || B > c->plan.desc.max_batch) return fail(c, VTI_ERR_ARG, std::string(fn) + ": B out of range (0..max_batch)");
+    if (!c->d_wpk) return fail(c, VTI_ERR_STATE, std::string(fn) + ": weights not loaded");
+    if (!c->ws) return fail(c, VTI_ERR_STATE, std::string(fn) + ": workspace not set");
+    return VTI_OK;
+}
+
+// Ultralytics LetterBox geometry (auto=False here: the model size HxW is fixed at vti_create).
+static void letterbox_geom(int H0, int W0, int H, int W, int& new_h, int& new_w, int& top, int& left) {
+    const double r = std::min((double)H / H0, (double)W / W0);
+    new_w = (int)std::nearbyint(W0 * r);
+    new_h = (int)std::nearbyint(H0 * r);
+    const double dw = (W - new_w) / 2.0, dh = (H - new_h) / 2.0;
+    top = (int)std::nearbyint(dh - 0.1);
+    left = (int)std::nearbyint(dw - 0.1);
+}
+
+int32_t vti_letterbox(vti_ctx* c, const uint8_t* frames, int32_t B, int32_t H0, int32_t W0, uint8_t* out, void* stream) {
+    if (!c || !frames || !out || H0 < 1 || W0 < 1 || B < 0) return fail(c, VTI_ERR_ARG, "vti_letterbox: bad argument");
+    int nh, nw, top, left;
+    letterbox_geom(H0, W0, c->plan.desc.H, c->plan.desc.W, nh, nw, top, left);
+    VTI_HIP(c, launch_letterbox(frames, B, H0, W0, out, c->plan.desc.H, c->plan.desc.W, nh, nw, top, left, (hipStream_t)stream),
+            "letterbox kernel");
+    return VTI_OK;
+}
+
+static void* buf_ptr(vti_ctx* c, int buf, const void* input, void* proto) {
+    if (buf == 0) return (void*)input;
+    if (buf == c->plan.proto_buf_c) return proto;
+    return c->ws + c->plan.bufs[buf].off;
+}
+
+int32_t vti_forward(vti_ctx* c, const uint8_t* input, int32_t B, int32_t swap_rb, float* pred, void* proto, void* stream) {
+    int32_t rc = check_ready(c, B, "vti_forward");
+    if (rc) return rc;
+    if (!input || !pred || !proto) return fail(c, VTI_ERR_ARG, "vti_forward: null pointer");
+    if (B == 0) return VTI_OK;
+    const Plan& P = c->plan;
+    hipStream_t st = (hipStream_t)stream;
+    const int dt = P.desc.dtype;
+    for (const Op& op : P.ops) {
+        switch (op.kind) {
+        case OP_CONV0:
+        case OP_CONV: {
+            const ConvRow& r = P.convs[op.conv];
+            const ConvCfg& g = op.cfg;
+            const Buf& ib = P.bufs[op.in.buf];
+            const Buf& ob = P.bufs[op.out.buf];
+            const bool deconv = r.kind == 2;
+            ConvParams p;
+            memset(&p, 0, sizeof p);
+            p.in = buf_ptr(c, op.in.buf, input, proto);
+            p.out = buf_ptr(c, op.out.buf, input, proto);
+            p.wpk = (const char*)c->d_wpk + g.wpk_off;
+            p.bias = c->d_bias + g.bias_off;
+            p.B = B; p.Hin = ib.H; p.Win = ib.W;
+            p.Hout = deconv ? ib.H : r.h_out; p.Wout = deconv ? ib.W : r.w_out;
+            p.Cin = r.c1; p.in_ld = ib.C; p.in_coff = op.in.coff;
+            p.Cout = g.gemm_n; p.out_ld = ob.C; p.out_coff = op.out.coff;
+            if (op.has_res) {
+                p.res = buf_ptr(c, op.res.buf, input, proto);
+                p.res_ld = P.bufs[op.res.buf].C; p.res_coff = op.res.coff; p.has_res = 1;
+            }
+            p.TH = g.TH; p.TW = g.TW;
+            p.tiles_y = (p.Hout + g.TH - 1) / g.TH; p.tiles_x = (p.Wout + g.TW - 1) / g.TW;
+            p.WN = g.WN;
+            p.act = r.kind == 0; p.out_f32 = op.out_f32 ? 1 : 0;
+            p.deconv_c = deconv ? r.c2 : 0;
+            p.swap_rb = swap_rb ? 1 : 0;
+            p.nchunks = g.nchunks; p.ntiles_n = g.ntiles_n;
+            p.scalar_store = (g.gemm_n % 4 || ob.C % 4 || op.out.coff % 4) ? 1 : 0;
+            const int ks = deconv ? 1 : r.k, s = deconv ? 1 : r.s;
+            VTI_HIP(c, launch_conv(dt, ks, s, g.NREP, op.kind == OP_CONV0 ? 1 : 0, p, g.lds, st), r.name.c_str());
+            break;
+        }
+        case OP_POOL: {
+            const Buf& ib = P.bufs[op.in.buf];
+            PoolParams p;
+            p.in = buf_ptr(c, op.in.buf, input, proto); p.out = p.in ? (void*)p.in : nullptr;
+            p.B = B; p.H = ib.H; p.W = ib.W; p.C = op.in.C; p.ld = ib.C; p.in_coff = op.in.coff; p.out_coff = op.out.coff;
+            VTI_HIP(c, launch_sppf_pool(dt, p, st), "sppf pool");
+            break;
+        }
+        case OP_UP2: {
+            const Buf& ib = P.bufs[op.in.buf];
+            const Buf& ob = P.bufs[op.out.buf];
+            Up2Params p;
+            p.in = buf_ptr(c, op.in.buf, input, proto); p.out = buf_ptr(c, op.out.buf, input, proto);
+            p.B = B; p.H = ib.H; p.W = ib.W; p.C = op.in.C; p.in_ld = ib.C; p.in_coff = op.in.coff;
+            p.out_ld = ob.C; p.out_coff = op.out.coff;
+            VTI_HIP(c, launch_upsample2x(dt, p, st), "upsample2x");
+            break;
+        }
+        case OP_DECODE: {
+            DecodeParams p;
+            memset(&p, 0, sizeof p);
+            int a0 = 0;
+            for (int l = 0; l < 3; ++l) {
+                const Level& lv = P.levels[l];
+                p.box[l] = (const float*)(c->ws + P.bufs[lv.box_buf].off);
+                p.cls[l] = (const float*)(c->ws + P.bufs[lv.cls_buf].off);
+                p.mc[l] = (const float*)(c->ws + P.bufs[lv.mc_buf].off);
+                p.H[l] = lv.H; p.W[l] = lv.W; p.stride[l] = lv.stride; p.a0[l] = a0;
+                a0 += lv.H * lv.W;
+            }
+            p.B = B; p.A = P.num_anchors; p.nc = P.desc.nc; p.nm = P.desc.nm; p.reg_max = P.desc.reg_max;
+            p.pred = pred;
+            VTI_HIP(c, launch_decode(p, st), "decode");
+            break;
+        }
+        }
+    }
+    c->last_input = input;
+    c->last_proto = proto;
+    return VTI_OK;
+}
+
+int32_t vti_nms(vti_ctx* c, const float* pred, int32_t B, float conf, double iou, int32_t max_det, int32_t agnostic,
+                float* dets, int32_t* counts, void* stream) {
+    if (!c) return VTI_ERR_ARG;
+    if (B < 0 || B > c->plan.desc.max_batch) return fail(c, VTI_ERR_ARG, "vti_nms: B out of range");
+    if (!c->ws) return fail(c, VTI_ERR_STATE, "vti_nms: workspace not set");
+    if (!pred || !dets || !counts || max_det < 1) return fail(c, VTI_ERR_ARG, "vti_nms: bad argument");
+    VTI_HIP(c, launch_nms(pred, B, c->plan.num_anchors, c->plan.desc.nc, c->plan.desc.nm, conf, iou, max_det, agnostic,
+                          dets, counts, c->ws + c->act_bytes, (hipStream_t)stream), "nms kernel");
+    return VTI_OK;
+}
+
+int32_t vti_masks(vti_ctx* c, const float* dets, const int32_t* counts, const void* proto, int32_t B, int32_t max_det,
+                  int32_t mode, int32_t packing, uint8_t* masks, int32_t capacity, int32_t* offsets, void* stream) {
+    if (!c || !dets || !counts || !proto || !offsets || B < 0 || max_det < 1 || capacity < 0 || (capacity && !masks))
+        return fail(c, VTI_ERR_ARG, "vti_masks: bad argument");
+    if ((mode != VTI_MASK_LOGIT && mode != VTI_MASK_SIGMOID) || (packing != VTI_PACK_U8 && packing != VTI_PACK_BITS))
+        return fail(c, VTI_ERR_ARG, "vti_masks: bad mode/packing");
+    if (capacity > 65535) return fail(c, VTI_ERR_UNSUPPORTED, "vti_masks: capacity above 65535 instances per call");
+    const vti_desc& d = c->plan.desc;
+    VTI_HIP(c, launch_masks(d.dtype, dets, counts, proto, B, max_det, d.nm, d.H / 4, d.W / 4, d.H, d.W, mode, packing, masks,
+                            capacity, offsets, (hipStream_t)stream), "mask kernel");
+    return VTI_OK;
+}
+
+int32_t vti_scale_boxes(vti_ctx* c, const float* dets, const int32_t* counts, int32_t B, int32_t max_det, int32_t H0,
+                        int32_t W0, float* xyxy, void* stream) {
+    if (!c || !dets || !counts || !xyxy || B < 0 || max_det < 1 || H0 < 1 || W0 < 1)
+        return fail(c, VTI_ERR_ARG, "vti_scale_boxes: bad argument");
+    const vti_desc& d = c->plan.desc;
+    VTI_HIP(c, launch_scale_boxes(dets, counts, B, max_det, d.nm, d.H, d.W, H0, W0, xyxy, (hipStream_t)stream), "scale_boxes kernel");
+    return VTI_OK;
+}
+
+int32_t vti_predict(vti_ctx* c, const uint8_t* frames, int32_t B, int32_t H0, int32_t W0, int32_t swap_rb, float conf,
+                    double iou, int32_t max_det, int32_t agnostic, int32_t mask_mode, int32_t packing,
+                    uint8_t* input_scratch, float* pred, void* proto, float* dets, int32_t* counts, uint8_t* masks,
+                    int32_t capacity, int32_t* offsets, float* xyxy, void* stream) {
+    int32_t rc = check_ready(c, B, "vti_predict");
+    if (rc) return rc;
+    const vti_desc& d = c->plan.desc;
+    const uint8_t* input = frames;
+    if (H0 != d.H || W0 != d.W) {
+        if (!input_scratch) return fail(c, VTI_ERR_ARG, "vti_predict: frames need letterboxing but dev_input_scratch is NULL");
+        rc = vti_letterbox(c, frames, B, H0, W0, input_scratch, stream);
+        if (rc) return rc;
+        input = input_scratch;
+    }
+    if ((rc = vti_forward(c, input, B, swap_rb, pred, proto, stream))) return rc;
+    if ((rc = vti_nms(c, pred, B, conf, iou, max_det, agnostic, dets, counts, stream))) return rc;
+    if ((rc = vti_masks(c, dets, counts, proto, B, max_det, mask_mode, packing, masks, capacity, offsets, stream))) return rc;
+    if (xyxy && (rc = vti_scale_boxes(c, dets, counts, B, max_det, H0, W0, xyxy, stream))) return rc;
+    return VTI_OK;
+}
+
+int32_t vti_mask_to_frame(vti_ctx* c, const uint8_t* masks, int32_t n, int32_t H, int32_t W, int32_t H0, int32_t W0,
+                          uint8_t* bitmaps, int32_t* nonzero, void* stream) {
+    if (!c || n < 0 || H < 1 || W < 1 || H0 < 1 || W0 < 1 || (n && (!masks || !bitmaps || !nonzero)))
+        return fail(c, VTI_ERR_ARG, "vti_mask_to_frame: bad argument");
+    VTI_HIP(c, launch_mask_to_frame(masks, n, H, W, H0, W0, bitmaps, nonzero, (hipStream_t)stream), "mask_to_frame kernel");
+    return VTI_OK;
+}
+
+int32_t vti_union_envelope(vti_ctx* c, const uint8_t* bitmaps, const int32_t* select, int32_t nsel, int32_t H0, int32_t W0,
+                           uint8_t* uni, int32_t* envelope, void* stream) {
+    if (!c || nsel < 0 || H0 < 1 || W0 < 1 || !uni || !envelope || (nsel && (!bitmaps || !select)))
+        return fail(c, VTI_ERR_ARG, "vti_union_envelope: bad argument");
+    VTI_HIP(c, launch_union_envelope(bitmaps, select, nsel, H0, W0, uni, envelope, (hipStream_t)stream), "union_envelope kernel");
+    return VTI_OK;
+}
+
+int32_t vti_mask_stats(vti_ctx* c, const uint8_t* bitmaps, int32_t n, int32_t H0, int32_t W0, int64_t* stats, void* stream) {
+    if (!c || n < 0 || H0 < 1 || W0 < 1 || (n && (!bitmaps || !stats)))
+        return fail(c, VTI_ERR_ARG, "vti_mask_stats: bad argument");
+    VTI_HIP(c, launch_mask_stats(bitmaps, n, H0, W0, (long long*)stats, (hipStream_t)stream), "mask_stats kernel");
+    return VTI_OK;
+}
+
+int32_t vti_debug_conv_output(vti_ctx* c, int32_t i, int32_t B, float* out, void* stream) {
+    int32_t rc = check_ready(c, B, "vti_debug_conv_output");
+    if (rc) return rc;
+    if (i < 0 || i >= (int32_t)c->plan.convs.size() || !out) return fail(c, VTI_ERR_ARG, "vti_debug_conv_output: bad argument");
+    const View& v = c->plan.conv_out[i];
+    const Buf& b = c->plan.bufs[v.buf];
+    const void* src = buf_ptr(c, v.buf, c->last_input, c->last_proto);
+    if (!src) return fail(c, VTI_ERR_STATE, "vti_debug_conv_output: run vti_forward first");
+    const int is_f32 = (b.elem == EL_F32) || (b.elem == EL_T && c->plan.desc.dtype == VTI_F32);
+    VTI_HIP(c, launch_debug_nchw(is_f32, src, B, b.H, b.W, v.C, b.C, v.coff, out, (hipStream_t)stream), "debug copy");
+    return VTI_OK;
+}
+
+}  // extern "C"

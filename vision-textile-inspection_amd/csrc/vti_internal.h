@@ -1,0 +1,135 @@
+// Internal declarations shared by the host-side plan/API (vti_api.cpp, plan.cpp, weights.cpp)
+// and the gfx950 kernels (conv.hip, misc.hip, post.hip).  Not part of the C ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/vti.h"
+
+namespace vti {
+
+// ---- plan ---------------------------------------------------------------------------
+enum ElemKind { EL_T = 0, EL_F32 = 1, EL_U8 = 2 };   // EL_T = ctx dtype (fp16 or fp32)
+
+struct Buf {             // one NHWC activation tensor [max_batch, H, W, C]
+    int C, H, W;
+    int elem;            // ElemKind
+    size_t off;          // byte offset inside the workspace
+    size_t bytes;        // for max_batch frames
+};
+
+struct View {            // channel slice of a Buf (concat-free C2f / neck)
+    int buf = -1, coff = 0, C = 0;
+};
+
+struct ConvRow {         // fused conv table, Ultralytics order
+    std::string name;
+    int c1, c2, k, s, kind;
+    int h_in, w_in, h_out, w_out;
+    int64_t macs() const {
+        const int64_t hw = (kind == 2) ? (int64_t)h_in * w_in : (int64_t)h_out * w_out;
+        return hw * c1 * c2 * k * k;
+    }
+    int64_t fused_params() const { return (int64_t)c1 * c2 * k * k + c2; }
+};
+
+enum OpKind { OP_CONV0, OP_CONV, OP_POOL, OP_UP2, OP_DECODE };
+
+struct ConvCfg {         // launch geometry chosen at plan time
+    int TH = 0, TW = 0;  // output tile (pixels)
+    int WN = 1;          // waves along Cout (1,2,4); 4/WN waves along pixels
+    int NREP = 1;        // 16-wide cout tiles per wave
+    int nchunks = 0;     // K chunks (32 ch fp16 / 16 ch fp32)
+    int ntiles_n = 0;    // ceil(gemmN/16)
+    int gemm_n = 0;      // Cout (deconv: 4*Cout)
+    size_t lds = 0;
+    size_t wpk_off = 0;  // byte offset of this conv's packed weights
+    size_t bias_off = 0; // float offset of this conv's bias
+};
+
+struct Op {
+    OpKind kind;
+    int conv = -1;       // index into convs (OP_CONV0 / OP_CONV)
+    View in, out, res;
+    bool has_res = false;
+    bool out_f32 = false;
+    ConvCfg cfg;
+};
+
+struct Level { int C, H, W, stride; int box_buf, cls_buf, mc_buf; };
+
+struct Plan {
+    vti_desc desc;
+    int esize = 2;                       // bytes per EL_T element
+    std::vector<ConvRow> convs;
+    std::vector<View> conv_out;          // where each conv's result lives (debug hook)
+    std::vector<Buf> bufs;
+    std::vector<Op> ops;
+    std::vector<Level> levels;
+    int proto_buf_c = 0;                 // npr
+    View proto_src;                      // input of proto.cv3 (so cv3 writes straight to the caller's proto)
+    int num_anchors = 0;
+    size_t ws_bytes = 0;
+    size_t wpk_bytes = 0, bias_floats = 0;
+    int64_t macs = 0, fused_params = 0;
+    std::string build(const vti_desc& d); // returns "" or an error message
+};
+
+// ---- kernel parameter blocks ------------------------------------------------------------
+struct ConvParams {
+    const void* in; void* out; const void* res; const void* wpk; const float* bias;
+    int B, Hin, Win, Hout, Wout;         // Hout/Wout: conv output grid (deconv: == Hin/Win, stores on the 2x grid)
+    int Cin, in_ld, in_coff;
+    int Cout;                            // GEMM N
+    int out_ld, out_coff, res_ld, res_coff;
+    int TH, TW, tiles_y, tiles_x, WN;
+    int act, out_f32, deconv_c, swap_rb, nchunks, ntiles_n, has_res, scalar_store;
+};
+
+// dtype: VTI_F16/VTI_F32; mode 0 = NHWC conv, 1 = conv0 (u8 input, im2col K=27->32)
+hipError_t launch_conv(int dtype, int ks, int stride, int nrep, int mode, const ConvParams& p,
+                       size_t lds_bytes, hipStream_t st);
+size_t conv_lds_bytes(int ks, int stride, int mode, int TH, int TW, int WN, int NREP);
+
+struct PoolParams { const void* in; void* out; int B, H, W, C, ld, in_coff, out_coff; };
+hipError_t launch_sppf_pool(int dtype, const PoolParams& p, hipStream_t st);
+
+struct Up2Params { const void* in; void* out; int B, H, W, C, in_ld, in_coff, out_ld, out_coff; };
+hipError_t launch_upsample2x(int dtype, const Up2Params& p, hipStream_t st);
+
+struct DecodeParams {
+    const float* box[3]; const float* cls[3]; const float* mc[3];
+    int H[3], W[3], stride[3], a0[3];
+    int B, A, nc, nm, reg_max;
+    float* pred;                          // [B, 4+nc+nm, A]
+};
+hipError_t launch_decode(const DecodeParams& p, hipStream_t st);
+
+hipError_t launch_debug_nchw(int elem_is_f32, const void* src, int B, int H, int W, int C, int ld, int coff,
+                             float* dst, hipStream_t st);
+
+// post-processing (post.hip)
+hipError_t launch_letterbox(const uint8_t* frames, int B, int H0, int W0, uint8_t* out, int H, int W,
+                            int new_h, int new_w, int top, int left, hipStream_t st);
+size_t nms_workspace_bytes(int B, int A);
+hipError_t launch_nms(const float* pred, int B, int A, int nc, int nm, float conf, double iou, int max_det,
+                      int agnostic, float* dets, int* counts, void* ws, hipStream_t st);
+hipError_t launch_masks(int dtype, const float* dets, const int* counts, const void* proto, int B, int max_det,
+                        int nm, int Hp, int Wp, int H, int W, int mode, int packing, uint8_t* masks,
+                        int capacity, int* offsets, hipStream_t st);
+hipError_t launch_scale_boxes(const float* dets, const int* counts, int B, int max_det, int nm, int H, int W,
+                              int H0, int W0, float* xyxy, hipStream_t st);
+hipError_t launch_mask_to_frame(const uint8_t* masks, int n, int H, int W, int H0, int W0, uint8_t* bitmaps,
+                                int* nonzero, hipStream_t st);
+hipError_t launch_union_envelope(const uint8_t* bitmaps, const int* select, int nsel, int H0, int W0,
+                                 uint8_t* uni, int* envelope, hipStream_t st);
+hipError_t launch_mask_stats(const uint8_t* bitmaps, int n, int H0, int W0, long long* stats, hipStream_t st);
+
+// weights.cpp: parse VTIW1 + pack into MFMA fragment order (host memory)
+std::string pack_weights(const Plan& plan, const void* blob, size_t nbytes,
+                         std::vector<uint8_t>& wpk, std::vector<float>& bias);
+
+}  // namespace vti

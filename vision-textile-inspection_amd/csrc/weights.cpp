@@ -1,0 +1,103 @@
+// VTIW1 container parsing and repacking into MFMA fragment order (host side).
+//
+// Stands in for the state-dict the reference obtains by unpickling its .pt
+// (measurement.py:145); tensor names follow Ultralytics' `model.{i}...` prefixes so a
+// converter can fill the container from a real checkpoint.
+//
+// Packed layout per conv (consumed by conv.hip):
+//   wpk[chunk][ntile][tap][lane 0..63][VEC]   VEC = 8 fp16 / 4 fp32 (16 B per lane)
+//   element = W[cout = ntile*16 + (lane&15)][cin = chunk*KC + (lane>>4)*VEC + j][tap]
+// i.e. one (chunk, ntile, tap) fragment is the 1 KiB a wave loads as the MFMA "A" operand
+// (rows = output channels), zero padded past Cout / Cin.
+#include <cstring>
+
+#include "vti_internal.h"
+
+namespace vti {
+
+namespace {
+struct Hdr { char magic[4]; uint32_t version; char scale[4]; uint32_t nc, nm, reg_max, n_convs; char pad[36]; };
+struct Rec { char name[48]; uint32_t c1, c2, k, s, kind; char pad[12]; };
+static_assert(sizeof(Hdr) == 64 && sizeof(Rec) == 80, "VTIW1 record sizes");
+}  // namespace
+
+std::string pack_weights(const Plan& plan, const void* blob, size_t nbytes, std::vector<uint8_t>& wpk,
+                         std::vector<float>& bias) {
+    const uint8_t* p = (const uint8_t*)blob;
+    if (!blob || nbytes < sizeof(Hdr)) return "weights: container too small";
+    Hdr h;
+    memcpy(&h, p, sizeof h);
+    if (memcmp(h.magic, "VTIW", 4) != 0 || h.version != 1) return "weights: not a VTIW1 container";
+    if (h.scale[0] != plan.desc.scale || (int)h.nc != plan.desc.nc || (int)h.nm != plan.desc.nm ||
+        (int)h.reg_max != plan.desc.reg_max)
+        return "weights: container scale/nc/nm/reg_max do not match the model description";
+    if (h.n_convs != plan.convs.size()) return "weights: conv count does not match the plan";
+
+    const bool f16 = plan.desc.dtype == VTI_F16;
+    const int KC = f16 ? 32 : 16, VEC = f16 ? 8 : 4;
+    wpk.assign(plan.wpk_bytes, 0);
+    bias.assign(plan.bias_floats, 0.f);
+
+    // conv index -> op (cfg)
+    std::vector<const Op*> op_of(plan.convs.size(), nullptr);
+    for (const Op& op : plan.ops)
+        if (op.kind == OP_CONV || op.kind == OP_CONV0) op_of[op.conv] = &op;
+
+    size_t off = sizeof(Hdr);
+    for (size_t i = 0; i < plan.convs.size(); ++i) {
+        const ConvRow& r = plan.convs[i];
+        if (off + sizeof(Rec) > nbytes) return "weights: truncated container";
+        Rec rec;
+        memcpy(&rec, p + off, sizeof rec);
+        off += sizeof rec;
+        char nm[49];
+        memcpy(nm, rec.name, 48); nm[48] = 0;
+        if (r.name != nm) return std::string("weights: expected conv '") + r.name + "' but found '" + nm + "'";
+        if ((int)rec.c1 != r.c1 || (int)rec.c2 != r.c2 || (int)rec.k != r.k || (int)rec.s != r.s || (int)rec.kind != r.kind)
+            return "weights: shape mismatch for " + r.name;
+        const size_t nw = (size_t)r.c1 * r.c2 * r.k * r.k;
+        if (off + 4 * (nw + r.c2) > nbytes) return "weights: truncated container";
+        std::vector<float> w(nw), b(r.c2);
+        memcpy(w.data(), p + off, 4 * nw); off += 4 * nw;
+        memcpy(b.data(), p + off, 4 * (size_t)r.c2); off += 4 * (size_t)r.c2;
+
+        const Op& op = *op_of[i];
+        const ConvCfg& c = op.cfg;
+        const bool conv0 = op.kind == OP_CONV0, deconv = r.kind == 2;
+        const int taps = (conv0 || deconv) ? 1 : r.k * r.k;
+        uint8_t* dst = wpk.data() + c.wpk_off;
+        for (int ck = 0; ck < c.nchunks; ++ck)
+            for (int nt = 0; nt < c.ntiles_n; ++nt)
+                for (int tap = 0; tap < taps; ++tap)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < VEC; ++j) {
+                            const int ng = nt * 16 + (lane & 15);
+                            const int kk = ck * KC + (lane >> 4) * VEC + j;
+                            float v = 0.f;
+                            if (ng < c.gemm_n) {
+                                if (conv0) {
+                                    if (kk < 27) {   // k = (kh*3+kw)*3 + channel
+                                        const int t = kk / 3, chn = kk % 3;
+                                        v = w[((size_t)ng * 3 + chn) * 9 + t];
+                                    }
+                                } else if (deconv) {
+                                    if (kk < r.c1) {   // gemm column = (dy*2+dx)*c2 + co ; torch IOHW
+                                        const int q = ng / r.c2, co = ng % r.c2;
+                                        v = w[((size_t)kk * r.c2 + co) * 4 + q];
+                                    }
+                                } else if (kk < r.c1) {
+                                    v = w[((size_t)ng * r.c1 + kk) * taps + tap];
+                                }
+                            }
+                            const size_t e = ((((size_t)ck * c.ntiles_n + nt) * taps + tap) * 64 + lane) * VEC + j;
+                            if (f16) ((_Float16*)dst)[e] = (_Float16)v;
+                            else ((float*)dst)[e] = v;
+                        }
+        float* bd = bias.data() + c.bias_off;
+        for (int n = 0; n < c.gemm_n; ++n) bd[n] = b[deconv ? n % r.c2 : n];
+    }
+    if (off != nbytes) return "weights: trailing bytes in container";
+    return "";
+}
+
+}  // namespace vti

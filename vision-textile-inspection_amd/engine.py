@@ -1,0 +1,233 @@
+"""Thin host wrapper around one libvti context: owns the torch-ROCm tensors the C ABI writes into.
+
+PyTorch is plumbing here (device memory + the current HIP stream); all arithmetic runs in
+libvti.so's HIP kernels.  Replaces the predictor object Ultralytics builds lazily on the first
+`model.predict(...)` (reference: measurement.py:208-210).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import VtiConvInfo, VtiDesc, check, lib
+
+DTYPES = {"fp16": _lib.VTI_F16, "f16": _lib.VTI_F16, "half": _lib.VTI_F16,
+          "fp32": _lib.VTI_F32, "f32": _lib.VTI_F32, "float": _lib.VTI_F32}
+MASK_MODES = {"logit": _lib.VTI_MASK_LOGIT, "sigmoid": _lib.VTI_MASK_SIGMOID}
+PACKINGS = {"u8": _lib.VTI_PACK_U8, "bits": _lib.VTI_PACK_BITS}
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class Engine:
+    """One (model description, input size, max batch, dtype) context."""
+
+    def __init__(self, scale="n", nc=80, nm=32, reg_max=16, H=640, W=640, max_batch=1, dtype="fp16"):
+        self.scale, self.nc, self.nm, self.reg_max = scale, nc, nm, reg_max
+        self.H, self.W, self.max_batch = H, W, max_batch
+        self.dtype = "fp16" if DTYPES[dtype] == _lib.VTI_F16 else "fp32"
+        self._ctx = C.c_void_p(0)
+        desc = VtiDesc(scale.encode()[:1], nc, nm, reg_max, H, W, max_batch, DTYPES[dtype])
+        rc = lib().vti_create(C.byref(desc), C.byref(self._ctx))
+        if rc != 0:
+            raise _lib.VtiError(rc, lib().vti_last_error(None).decode())
+        self.device = None
+        self._ws = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "_ctx", None) and self._ctx.value:
+                lib().vti_destroy(self._ctx)
+                self._ctx = C.c_void_p(0)
+        except Exception:
+            pass
+
+    # ---- host-only plan introspection ------------------------------------------------
+    def conv_table(self):
+        out = []
+        info = VtiConvInfo()
+        for i in range(lib().vti_num_convs(self._ctx)):
+            check(self._ctx, lib().vti_conv_at(self._ctx, i, C.byref(info)))
+            out.append(dict(name=info.name.decode(), c1=info.c1, c2=info.c2, k=info.k, s=info.s, kind=info.kind,
+                            h_in=info.h_in, w_in=info.w_in, h_out=info.h_out, w_out=info.w_out, macs=info.macs,
+                            tile=(info.tile_h, info.tile_w), waves_n=info.waves_n, nrep=info.nrep, lds=info.lds_bytes))
+        return out
+
+    @property
+    def num_anchors(self):
+        return lib().vti_num_anchors(self._ctx)
+
+    @property
+    def fused_params(self):
+        return lib().vti_fused_params(self._ctx)
+
+    @property
+    def macs_per_frame(self):
+        return lib().vti_macs_per_frame(self._ctx)
+
+    @property
+    def workspace_bytes(self):
+        return lib().vti_workspace_bytes(self._ctx)
+
+    @property
+    def num_launches(self):
+        return lib().vti_num_launches(self._ctx)
+
+    @property
+    def no(self):
+        return 4 + self.nc + self.nm
+
+    @property
+    def torch_dtype(self):
+        return torch.float16 if self.dtype == "fp16" else torch.float32
+
+    # ---- device setup ------------------------------------------------------------------
+    def load_weights(self, blob, device=0):
+        """blob: bytes of a VTIW1 container.  Uploads to `device` and allocates the workspace."""
+        if not torch.cuda.is_available():
+            raise RuntimeError("vti_amd needs a ROCm GPU: torch.cuda.is_available() is False (no CPU fallback)")
+        dev = torch.device("cuda", device) if isinstance(device, int) else torch.device(device)
+        torch.cuda.set_device(dev)
+        buf = (C.c_char * len(blob)).from_buffer_copy(blob)
+        check(self._ctx, lib().vti_load_weights(self._ctx, buf, len(blob), dev.index or 0))
+        self.device = dev
+        self._ws = torch.empty(self.workspace_bytes + 256, dtype=torch.uint8, device=dev)
+        base = self._ws.data_ptr()
+        aligned = (base + 255) & ~255
+        check(self._ctx, lib().vti_set_workspace(self._ctx, C.c_void_p(aligned), self.workspace_bytes))
+        return self
+
+    # ---- stages ------------------------------------------------------------------------
+    def letterbox(self, frames):
+        """frames: u8 [B,H0,W0,3] on device -> u8 [B,H,W,3]."""
+        B, H0, W0, _ = frames.shape
+        out = torch.empty((B, self.H, self.W, 3), dtype=torch.uint8, device=frames.device)
+        check(self._ctx, lib().vti_letterbox(self._ctx, _ptr(frames), B, H0, W0, _ptr(out), _stream()))
+        return out
+
+    def forward(self, inp, swap_rb=True, pred=None, proto=None):
+        """inp: u8 [B,H,W,3] letterboxed -> pred f32 [B,4+nc+nm,A], proto T [B,H/4,W/4,nm] (NHWC)."""
+        self._check_input(inp, (self.H, self.W))
+        B = inp.shape[0]
+        if pred is None:
+            pred = torch.empty((B, self.no, self.num_anchors), dtype=torch.float32, device=inp.device)
+        if proto is None:
+            proto = torch.empty((B, self.H // 4, self.W // 4, self.nm), dtype=self.torch_dtype, device=inp.device)
+        check(self._ctx, lib().vti_forward(self._ctx, _ptr(inp), B, int(bool(swap_rb)), _ptr(pred), _ptr(proto), _stream()))
+        return pred, proto
+
+    def nms(self, pred, conf=0.25, iou=0.7, max_det=300, agnostic=False, dets=None, counts=None):
+        B = pred.shape[0]
+        if dets is None:
+            dets = torch.empty((B, max_det, 6 + self.nm), dtype=torch.float32, device=pred.device)
+        if counts is None:
+            counts = torch.empty((B,), dtype=torch.int32, device=pred.device)
+        check(self._ctx, lib().vti_nms(self._ctx, _ptr(pred), B, float(conf), float(iou), int(max_det), int(bool(agnostic)),
+                                       _ptr(dets), _ptr(counts), _stream()))
+        return dets, counts
+
+    def masks(self, dets, counts, proto, mode="logit", packing="u8", capacity=None, masks=None, offsets=None):
+        """-> (masks u8 [capacity,H,W] or [capacity,H,W/8], offsets i32 [B+1]).  With capacity=None the
+        detection counts are read back first (one small D2H sync) to size the output exactly."""
+        B, max_det = dets.shape[0], dets.shape[1]
+        if capacity is None:
+            capacity = int(counts.clamp(0, max_det).sum().item())
+        wb = self.W if packing == "u8" else self.W // 8
+        if masks is None:
+            masks = torch.empty((capacity, self.H, wb), dtype=torch.uint8, device=dets.device)
+        if offsets is None:
+            offsets = torch.empty((B + 1,), dtype=torch.int32, device=dets.device)
+        check(self._ctx, lib().vti_masks(self._ctx, _ptr(dets), _ptr(counts), _ptr(proto), B, max_det, MASK_MODES[mode],
+                                         PACKINGS[packing], _ptr(masks) if capacity else C.c_void_p(0), capacity,
+                                         _ptr(offsets), _stream()))
+        return masks, offsets
+
+    def scale_boxes(self, dets, counts, H0, W0, xyxy=None):
+        B, max_det = dets.shape[0], dets.shape[1]
+        if xyxy is None:
+            xyxy = torch.empty((B, max_det, 4), dtype=torch.float32, device=dets.device)
+        check(self._ctx, lib().vti_scale_boxes(self._ctx, _ptr(dets), _ptr(counts), B, max_det, H0, W0, _ptr(xyxy), _stream()))
+        return xyxy
+
+    def alloc_outputs(self, B, max_det, capacity, packing="bits", device=None):
+        """Preallocated output set for predict_into (the no-sync, graph-friendly form)."""
+        dev = device or self.device
+        wb = self.W if packing == "u8" else self.W // 8
+        return dict(
+            pred=torch.empty((B, self.no, self.num_anchors), dtype=torch.float32, device=dev),
+            proto=torch.empty((B, self.H // 4, self.W // 4, self.nm), dtype=self.torch_dtype, device=dev),
+            dets=torch.empty((B, max_det, 6 + self.nm), dtype=torch.float32, device=dev),
+            counts=torch.empty((B,), dtype=torch.int32, device=dev),
+            masks=torch.empty((capacity, self.H, wb), dtype=torch.uint8, device=dev),
+            offsets=torch.empty((B + 1,), dtype=torch.int32, device=dev),
+            xyxy=torch.empty((B, max_det, 4), dtype=torch.float32, device=dev),
+            input=torch.empty((B, self.H, self.W, 3), dtype=torch.uint8, device=dev),
+        )
+
+    def predict_into(self, frames, out, conf=0.25, iou=0.7, max_det=300, agnostic=False, swap_rb=True,
+                     mask_mode="logit", packing="bits"):
+        """Whole pipeline (letterbox -> net -> NMS -> masks -> scale_boxes) on the current stream with
+        no host synchronisation; `out` from alloc_outputs()."""
+        B, H0, W0, _ = frames.shape
+        capacity = out["masks"].shape[0]
+        check(self._ctx, lib().vti_predict(
+            self._ctx, _ptr(frames), B, H0, W0, int(bool(swap_rb)), float(conf), float(iou), int(max_det),
+            int(bool(agnostic)), MASK_MODES[mask_mode], PACKINGS[packing], _ptr(out["input"]), _ptr(out["pred"]),
+            _ptr(out["proto"]), _ptr(out["dets"]), _ptr(out["counts"]), _ptr(out["masks"]), capacity,
+            _ptr(out["offsets"]), _ptr(out["xyxy"]), _stream()))
+        return out
+
+    # ---- consumer-side reductions (measurement.py:70-86,160-185,300-330) ----------------
+    def mask_to_frame(self, masks_u8, H0, W0):
+        n, H, W = masks_u8.shape
+        bitmaps = torch.empty((n, H0, W0), dtype=torch.uint8, device=masks_u8.device)
+        nonzero = torch.empty((n,), dtype=torch.int32, device=masks_u8.device)
+        check(self._ctx, lib().vti_mask_to_frame(self._ctx, _ptr(masks_u8), n, H, W, H0, W0, _ptr(bitmaps), _ptr(nonzero), _stream()))
+        return bitmaps, nonzero
+
+    def union_envelope(self, bitmaps, select):
+        n, H0, W0 = bitmaps.shape
+        sel = torch.as_tensor(select, dtype=torch.int32, device=bitmaps.device)
+        uni = torch.empty((H0, W0), dtype=torch.uint8, device=bitmaps.device)
+        env = torch.empty((W0,), dtype=torch.int32, device=bitmaps.device)
+        check(self._ctx, lib().vti_union_envelope(self._ctx, _ptr(bitmaps), _ptr(sel), sel.numel(), H0, W0, _ptr(uni), _ptr(env), _stream()))
+        return uni, env
+
+    def mask_stats(self, bitmaps):
+        n, H0, W0 = bitmaps.shape
+        stats = torch.empty((n, 5), dtype=torch.int64, device=bitmaps.device)
+        check(self._ctx, lib().vti_mask_stats(self._ctx, _ptr(bitmaps), n, H0, W0, _ptr(stats), _stream()))
+        return stats
+
+    # ---- test hook ---------------------------------------------------------------------
+    def debug_conv_output(self, i, B):
+        t = self.conv_table()[i]
+        out = torch.empty((B, t["c2"], t["h_out"], t["w_out"]), dtype=torch.float32, device=self.device)
+        check(self._ctx, lib().vti_debug_conv_output(self._ctx, i, B, _ptr(out), _stream()))
+        return out
+
+    def _check_input(self, t, hw):
+        if t.dtype != torch.uint8 or t.dim() != 4 or t.shape[3] != 3 or tuple(t.shape[1:3]) != tuple(hw):
+            raise ValueError(f"expected uint8 [B,{hw[0]},{hw[1]},3], got {t.dtype} {tuple(t.shape)}")
+        if not t.is_cuda or not t.is_contiguous():
+            raise ValueError("input must be a contiguous device tensor")
+        if t.shape[0] > self.max_batch:
+            raise ValueError(f"batch {t.shape[0]} exceeds max_batch {self.max_batch}")
+
+
+def unpack_bits(bits, W):
+    """u8 [...,W/8] LSB-first -> u8 [...,W] of 0/1 (host-side convenience for bit-packed masks)."""
+    b = bits.unsqueeze(-1)
+    sh = torch.arange(8, device=bits.device, dtype=torch.uint8)
+    return ((b >> sh) & 1).reshape(*bits.shape[:-1], W)
+
+
+def to_numpy(t):
+    return t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
