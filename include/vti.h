@@ -151,6 +151,19 @@ int32_t vti_mask_stats(vti_ctx* ctx, const uint8_t* dev_bitmaps, int32_t n, int3
  * f32 NCHW [B,c2,h_out,w_out] (test hook; not on the hot path). */
 int32_t vti_debug_conv_output(vti_ctx* ctx, int32_t i, int32_t B, float* dev_out, void* stream);
 
+/* Runs ONE convolution of the engine's conv family on caller tensors (kernel unit tests and
+ * micro-benchmarks; synchronous, allocates its own packed weights -- not on the hot path).
+ * dev_in: T NHWC [B,H,W,in_ld] (or u8 [B,H,W,3] when c1==3, the stem conv); host_w: f32 OIHW
+ * (kind 2: IOHW) in HOST memory; dev_out: T (or f32 if out_f32) NHWC with row pitch out_ld.
+ * tile_h/tile_w/waves_n/nrep = 0 lets the planner choose; iters > 1 times iters-1 launches with
+ * HIP events into *ms_out; cfg_out[5] receives {tile_h, tile_w, waves_n, nrep, lds_bytes}. */
+int32_t vti_debug_conv2d(int32_t dtype, const void* dev_in, int32_t B, int32_t H, int32_t W, int32_t in_ld,
+                         int32_t in_coff, int32_t c1, const float* host_w, const float* host_b, int32_t c2,
+                         int32_t k, int32_t s, int32_t kind, const void* dev_res, int32_t res_ld, int32_t res_coff,
+                         void* dev_out, int32_t out_ld, int32_t out_coff, int32_t out_f32, int32_t swap_rb,
+                         int32_t tile_h, int32_t tile_w, int32_t waves_n, int32_t nrep, int32_t iters,
+                         float* ms_out, int32_t* cfg_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

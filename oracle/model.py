@@ -8,6 +8,7 @@ ATen CPU kernels Ultralytics' CPU path dispatches to (F.conv2d, F.max_pool2d,
 F.conv_transpose2d, F.interpolate, F.silu, softmax).
 
 mode="fp32": plain fp32 everywhere (the reference's CPU numerics).
+mode="fp64": same fp32 weights and input, every op evaluated in double (measures the fp32 noise floor).
 mode="fp16": emulates the GPU engine's fp16 storage -- weights and every stored
   activation are rounded to fp16 at exactly the points the engine rounds (after
   bias+SiLU(+residual) of each conv, after the deconv, input after /255); all
@@ -34,9 +35,12 @@ class OracleModel:
             c1, c2, k, s, kind, w, b = convs[r.name]
             assert (c1, c2, k, s, kind) == (r.c1, r.c2, r.k, r.s, r.kind), r.name
             w = torch.from_numpy(w.copy())
+            b = torch.from_numpy(b.copy())
             if mode == "fp16":
                 w = w.half().float()
-            self.p[r.name] = (w, torch.from_numpy(b.copy()), k, s, kind)
+            if mode == "fp64":
+                w, b = w.double(), b.double()
+            self.p[r.name] = (w, b, k, s, kind)
         self.taps = None  # optional dict name -> activation, filled when forward(record=True)
 
     # -- rounding point ---------------------------------------------------
@@ -147,4 +151,6 @@ class OracleModel:
             x = x.flip(-1)
         x = x.permute(0, 3, 1, 2).contiguous().float() / 255
         x = self.q(x)
+        if self.mode == "fp64":
+            x = x.double()
         return self.head(self.features(x))

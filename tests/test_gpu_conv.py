@@ -1,0 +1,115 @@
+"""Kernel-level parity of the MFMA conv family (conv.hip) through vti_debug_conv2d.
+
+Exact-integer cases: operands are small integers so every product and partial sum is exactly
+representable -- the HIP result must equal the CPU convolution BIT FOR BIT, for every kernel
+variant (1x1, 3x3 s1, 3x3 s2, ConvTranspose 2x2, stem), wave split, register tile, ragged
+spatial size, channel remainder and channel-slice offset.  Operands are asymmetric random ints,
+so a transposed fragment or swapped operand cannot pass."""
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import need_gpu, ref_conv
+
+pytestmark = pytest.mark.gpu
+
+
+def _ints(rng, shape, lo, hi):
+    return rng.integers(lo, hi + 1, shape).astype(np.float32)
+
+
+CASES = [
+    # k, s, kind, c1, c2, H, W, forced (wn, nrep), extras
+    (1, 1, 1, 32, 32, 16, 20, (0, 0), {}),
+    (1, 1, 1, 48, 32, 12, 20, (1, 2), {}),                      # channel remainder chunk (48 = 32 + 16)
+    (1, 1, 1, 128, 256, 8, 20, (4, 4), {}),                     # waves split along Cout, grid.y = 1
+    (1, 1, 1, 64, 256, 8, 20, (4, 2), {}),                      # grid.y = 2
+    (1, 1, 1, 64, 2, 7, 9, (0, 0), {"out_f32": True}),          # nc=2 head: scalar-store path, ragged
+    (3, 1, 1, 16, 16, 20, 16, (1, 1), {}),                      # half-empty K chunk
+    (3, 1, 1, 64, 80, 16, 20, (1, 5), {}),                      # NREP 5 (cls tower)
+    (3, 1, 1, 80, 80, 10, 20, (1, 5), {}),                      # 80 = 2.5 chunks
+    (3, 1, 1, 32, 32, 23, 30, (0, 0), {}),                      # ragged tiles (736x960 feature map)
+    (3, 1, 1, 128, 128, 20, 20, (2, 2), {}),
+    (3, 1, 1, 64, 64, 9, 11, (2, 2), {"res": True}),            # bottleneck residual
+    (3, 2, 1, 32, 64, 40, 40, (2, 2), {}),
+    (3, 2, 1, 16, 32, 32, 32, (2, 1), {}),
+    (3, 2, 1, 128, 256, 21, 19, (0, 0), {}),                    # odd input, stride 2
+    (2, 2, 2, 64, 64, 10, 12, (0, 0), {}),                      # ConvTranspose2d(2,2): scattered stores
+    (2, 2, 2, 192, 192, 6, 5, (0, 0), {}),                      # m-scale proto upsample
+    (1, 1, 1, 32, 32, 16, 20, (1, 2), {"in_coff": 16, "in_ld": 64, "out_coff": 32, "out_ld": 96}),   # concat slices
+    (3, 1, 1, 32, 48, 12, 12, (1, 3), {"in_coff": 32, "in_ld": 64}),
+]
+
+
+@pytest.mark.parametrize("dtype", ["fp16", "fp32"])
+@pytest.mark.parametrize("case", CASES, ids=lambda c: f"k{c[0]}s{c[1]}kind{c[2]}_{c[3]}to{c[4]}_{c[5]}x{c[6]}_wn{c[7][0]}n{c[7][1]}")
+def test_conv_exact_integers(case, dtype):
+    need_gpu()
+    import vti_amd
+    k, s, kind, c1, c2, H, W, (wn, nrep), ex = case
+    rng = np.random.default_rng(hash((k, s, kind, c1, c2, H, W)) % (2 ** 32))
+    B = 2
+    in_ld, in_coff = ex.get("in_ld", c1), ex.get("in_coff", 0)
+    x_full = _ints(rng, (B, H, W, in_ld), -2, 2)
+    x = x_full[..., in_coff:in_coff + c1]
+    wshape = (c1, c2, k, k) if kind == 2 else (c2, c1, k, k)
+    w = _ints(rng, wshape, -1, 1)
+    b = _ints(rng, (c2,), -3, 3)
+    tdt = torch.float16 if dtype == "fp16" else torch.float32
+    xd = torch.from_numpy(x_full).to(tdt).cuda()
+    Ho, Wo = (2 * H, 2 * W) if kind == 2 else ((H + 2 * (k // 2) - k) // s + 1, (W + 2 * (k // 2) - k) // s + 1)
+    res = resd = None
+    if ex.get("res"):
+        res = _ints(rng, (B, Ho, Wo, c2), -4, 4)
+        resd = torch.from_numpy(res).to(tdt).cuda()
+    out, _, cfg = vti_amd.debug_conv2d(xd, w, b, k, s, kind, dtype, res=resd, in_coff=in_coff, c1=c1,
+                                       out_coff=ex.get("out_coff", 0), out_ld=ex.get("out_ld"),
+                                       out_f32=ex.get("out_f32", False), waves_n=wn, nrep=nrep)
+    torch.cuda.synchronize()
+    ref = ref_conv(x, w, b, k, s, kind, dtype, res=res, act=False)
+    oc = ex.get("out_coff", 0)
+    got = out.float().cpu()
+    assert torch.equal(got[..., oc:oc + c2], ref), f"cfg={cfg} max|d|={(got[..., oc:oc + c2] - ref).abs().max()}"
+    if oc:      # neighbours of the written channel slice stay untouched
+        assert (got[..., :oc] == 0).all() and (got[..., oc + c2:] == 0).all()
+
+
+@pytest.mark.parametrize("dtype,tol", [("fp16", 2e-3), ("fp32", 2e-6)])
+def test_conv_silu_random(dtype, tol):
+    """Random operands + fused bias/SiLU/residual epilogue: within rounding of the CPU op."""
+    need_gpu()
+    import vti_amd
+    rng = np.random.default_rng(7)
+    B, H, W, c1, c2 = 2, 24, 20, 64, 64
+    x = rng.standard_normal((B, H, W, c1)).astype(np.float32)
+    w = (rng.standard_normal((c2, c1, 3, 3)) / np.sqrt(9 * c1)).astype(np.float32)
+    b = rng.standard_normal(c2).astype(np.float32) * 0.1
+    res = rng.standard_normal((B, H, W, c2)).astype(np.float32)
+    tdt = torch.float16 if dtype == "fp16" else torch.float32
+    out, _, _ = vti_amd.debug_conv2d(torch.from_numpy(x).to(tdt).cuda(), w, b, 3, 1, 0, dtype,
+                                     res=torch.from_numpy(res).to(tdt).cuda())
+    ref = ref_conv(x, w, b, 3, 1, 0, dtype, res=res)
+    if dtype == "fp16":
+        ref = ref.half().float()
+    err = (out.float().cpu() - ref).abs().max().item()
+    assert err < tol * max(1.0, ref.abs().max().item()), err
+
+
+@pytest.mark.parametrize("dtype,tol", [("fp16", 1e-3), ("fp32", 1e-6)])
+@pytest.mark.parametrize("swap", [False, True])
+def test_stem_conv_u8(dtype, tol, swap):
+    """model.0: u8 HWC3 frame -> /255 -> 3x3 s2 conv (+ channel flip), ragged size."""
+    need_gpu()
+    import vti_amd
+    rng = np.random.default_rng(11)
+    B, H, W, c2 = 2, 46, 62, 16
+    x = rng.integers(0, 256, (B, H, W, 3), dtype=np.uint8)
+    w = (rng.standard_normal((c2, 3, 3, 3)) / np.sqrt(27)).astype(np.float32)
+    b = rng.standard_normal(c2).astype(np.float32) * 0.1
+    out, _, _ = vti_amd.debug_conv2d(torch.from_numpy(x).cuda(), w, b, 3, 2, 0, dtype, c1=3, swap_rb=swap)
+    xin = (x[..., ::-1] if swap else x).astype(np.float32) / np.float32(255)
+    ref = ref_conv(xin, w, b, 3, 2, 0, dtype)
+    if dtype == "fp16":
+        ref = ref.half().float()
+    err = (out.float().cpu() - ref).abs().max().item()
+    assert out.shape == (B, 23, 31, c2) and err < tol * max(1.0, ref.abs().max().item()), err

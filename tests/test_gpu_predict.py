@@ -1,0 +1,108 @@
+"""End-to-end predict() through the YOLO/Results mirror of the reference protocol
+(measurement.py:145,208-211,242-245; Utils/check_model.py:170-209) against the oracle pipeline."""
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import frames_u8, mask_iou, need_gpu
+from oracle import consumer as oc
+from oracle.letterbox import letterbox
+from oracle.model import OracleModel
+from oracle.postproc import non_max_suppression, process_mask, scale_boxes
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_predict(blob, frame, imgsz, conf, iou, max_det, nc, mode):
+    lb, g = letterbox(frame, imgsz)
+    om = OracleModel(blob, g["H"], g["W"], mode)
+    pred, proto = om.forward_u8(lb[None], swap_rb=True)
+    det = non_max_suppression(pred.numpy(), conf, iou, max_det, nc=nc)[0]
+    if len(det) == 0:
+        return det, None, None
+    masks = process_mask(proto[0], det[:, 6:], det[:, :4], (g["H"], g["W"]), "logit").numpy()
+    return det, masks, scale_boxes((g["H"], g["W"]), det[:, :4], frame.shape[:2])
+
+
+def _calibrated_model(vti_amd, nc, dtype, frame, imgsz, conf, target=400):
+    """Random nets with the stock class prior detect nothing; shift the class bias so that about
+    `target` anchors clear `conf` (done with the GPU path only)."""
+    m0 = vti_amd.YOLO(None, scale="n", nc=nc, seed=1, cls_bias=0.0, dtype=dtype, max_batch=2)
+    H, W = vti_amd.letterbox_shape(*frame.shape[:2], imgsz)
+    eng = m0._engine(H, W, 1)
+    x = torch.from_numpy(frame[None]).cuda()
+    inp = x if frame.shape[:2] == (H, W) else eng.letterbox(x)
+    pred, _ = eng.forward(inp)
+    p = pred[0, 4:4 + nc].amax(0).clamp(1e-6, 1 - 1e-6)
+    logit = torch.log(p / (1 - p))
+    kth = torch.topk(logit, target).values[-1].item()
+    bias = float(np.log(conf / (1 - conf)) - kth)
+    return vti_amd.YOLO(None, scale="n", nc=nc, seed=1, cls_bias=bias, dtype=dtype, max_batch=2)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "fp16"])
+def test_predict_reference_call_shape(dtype):
+    """The reference's own call: 1280x960 frame, conf 0.20, iou 0.25, max_det 200, imgsz 960, nc=2
+    (measurement.py:208-210, config.py:69-73)."""
+    need_gpu()
+    import vti_amd
+    frame = frames_u8(1, 960, 1280, seed=21)[0]
+    model = _calibrated_model(vti_amd, 2, dtype, frame, 960, 0.20)
+    results = model.predict(frame, verbose=False, conf=0.20, iou=0.25, max_det=200, imgsz=960)
+    r = results[0]
+    assert len(results) == 1 and r.boxes is not None
+    det, omasks, oxyxy = _oracle_predict(model._blob, frame, 960, 0.20, 0.25, 200, 2, dtype)
+    n = len(r.boxes)
+    assert n > 0 and r.masks is not None and r.masks.data.shape == (n, 736, 960) and r.masks.data.dtype == torch.float32
+    cls, xyxy, conf = r.boxes.cls.cpu().numpy(), r.boxes.xyxy.cpu().numpy(), r.boxes.conf.cpu().numpy()
+    assert (np.diff(conf) <= 0).all() and xyxy.min() >= 0 and xyxy[:, [0, 2]].max() <= 1280 and xyxy[:, [1, 3]].max() <= 960
+    if dtype == "fp32":
+        assert n == len(det) and np.array_equal(cls, det[:, 5])
+        assert np.abs(xyxy - oxyxy).max() < 5e-3 and np.abs(xyxy - oxyxy).max() / 1280 < 1e-3
+        assert np.abs(conf - det[:, 4]).max() < 1e-4
+        got = r.masks.data.cpu().numpy()
+        assert min(mask_iou(got[i], omasks[i]) for i in range(n)) >= 0.999
+    else:   # fp16 storage vs fp16-emulating oracle: near-tie NMS decisions may differ, so match by box
+        matched = 0
+        for i in range(len(det)):
+            j = np.abs(xyxy - oxyxy[i]).max(1).argmin()
+            if np.abs(xyxy[j] - oxyxy[i]).max() < 4.0 and cls[j] == det[i, 5]:
+                matched += 1
+        assert matched >= 0.9 * len(det), (matched, len(det), n)
+    # consumer side, exactly as measurement.py:249-330 walks the results
+    keep, ib = oc.roi_keep(xyxy, 960, 1280)
+    eng = model._engine(736, 960, 1)
+    bm, nz = vti_amd.consumer.instance_bitmaps(eng, r, 960, 1280)
+    assert bm.shape == (n, 960, 1280)
+    first = vti_amd.consumer.get_instance_mask_as_bitmap(eng, r, 0, 960, 1280)
+    ref0 = oc.instance_bitmap(r.masks.data[0].cpu().numpy(), 960, 1280)
+    assert (first is None) == (ref0 is None) and (first is None or np.array_equal(first.cpu().numpy(), ref0))
+
+
+def test_predict_batch_640_and_empty_results():
+    need_gpu()
+    import vti_amd
+    fr = frames_u8(3, 640, 640, seed=22)
+    model = _calibrated_model(vti_amd, 80, "fp16", fr[0], 640, 0.25)
+    res = model(fr, conf=0.25, iou=0.7)                       # __call__ alias, batched ndarray
+    assert len(res) == 3 and all(len(r.boxes) > 0 for r in res)
+    one = model.predict(source=fr[1])                          # keyword `source=` as check_model.py:331
+    assert torch.equal(one[0].boxes.data, res[1].boxes.data)
+    assert torch.equal(one[0].masks.data_u8, res[1].masks.data_u8)
+    assert model.names[0] == "class0" and len(model.names) == 80
+    quiet = model.predict(fr[0], conf=0.999999)
+    assert len(quiet[0].boxes) == 0 and quiet[0].masks is None and quiet[0].boxes.xyxy.shape == (0, 4)
+
+
+def test_predict_errors_raise_not_abort():
+    need_gpu()
+    import vti_amd
+    model = vti_amd.YOLO(None, scale="n", nc=2, dtype="fp16", max_batch=1)
+    with pytest.raises(ValueError):
+        model.predict(np.zeros((64, 64), np.uint8))
+    with pytest.raises(ValueError):
+        model.predict(np.zeros((64, 64, 3), np.float32))
+    with pytest.raises(ValueError):
+        model.predict()
+    with pytest.raises((vti_amd.VtiError, ValueError)):
+        vti_amd.YOLO(b"not a container")

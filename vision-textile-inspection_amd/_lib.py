@@ -61,6 +61,9 @@ SIGNATURES = {
     "vti_union_envelope": (_I32, [_P, _P, _P, _I32, _I32, _I32, _P, _P, _P]),
     "vti_mask_stats": (_I32, [_P, _P, _I32, _I32, _I32, _P, _P]),
     "vti_debug_conv_output": (_I32, [_P, _I32, _I32, _P, _P]),
+    "vti_debug_conv2d": (_I32, [_I32, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P, _I32, _I32, _I32, _I32,
+                                _P, _I32, _I32, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32,
+                                _P, _P, _P]),
 }
 
 _lib = None

@@ -87,49 +87,51 @@ struct Builder {
     }
 };
 
+}  // namespace
+
 // Pick the launch geometry for one conv.  Templates fix MREP=5 (80 pixels per wave along M);
 // WN in {1,2,4} splits the 4 waves between pixels and couts; the pixel tile is TH x TW.
-void choose_cfg(const Plan& P, Op& op) {
-    const ConvRow& r = P.convs[op.conv];
-    ConvCfg& c = op.cfg;
-    const bool f16 = P.desc.dtype == VTI_F16;
+void choose_conv_cfg(int dtype, const ConvRow& r, bool conv0, int max_batch, ConvCfg& c, int fth, int ftw, int fwn,
+                     int fnrep) {
+    const bool f16 = dtype == VTI_F16;
     const int KC = f16 ? 32 : 16;
-    const bool conv0 = op.kind == OP_CONV0;
     const bool deconv = r.kind == 2;
     c.gemm_n = deconv ? 4 * r.c2 : r.c2;
     c.ntiles_n = (c.gemm_n + 15) / 16;
     c.nchunks = conv0 ? (32 / KC) : (r.c1 + KC - 1) / KC;
     const int ks = deconv ? 1 : r.k, st = deconv ? 1 : r.s;
     const int Ho = deconv ? r.h_in : r.h_out, Wo = deconv ? r.w_in : r.w_out;
-    const int taps = conv0 ? 1 : ks * ks;
+    c.TH = c.TW = 0;
 
     double best = -1;
     for (int WN = 1; WN <= 4; WN *= 2) {
+        if (fwn && WN != fwn) continue;
         for (int NREP = 1; NREP <= 5; ++NREP) {
+            if (fnrep && NREP != fnrep) continue;
             const int BN = WN * NREP;                    // n-tiles per workgroup
             const int gy = (c.ntiles_n + BN - 1) / BN;
             const double n_eff = (double)c.ntiles_n / (gy * BN);
-            if (n_eff < 0.74) continue;
+            if (n_eff < 0.74 && !fnrep) continue;
             const int BM = (4 / WN) * 80;
-            // best pixel tile for this BM
             for (int TW = std::min(Wo, BM); TW >= 1; --TW) {   // widest first: ties keep row-contiguous tiles
-                const int TH = std::min(Ho, BM / TW);
+                if (ftw && TW != ftw) continue;
+                int TH = std::min(Ho, BM / TW);
+                if (fth) { if (fth * TW > BM) continue; TH = fth; }
                 if (TH < 1) continue;
                 const int tiles = ((Ho + TH - 1) / TH) * ((Wo + TW - 1) / TW);
                 const double m_eff = (double)Ho * Wo / ((double)tiles * BM);
                 const int PH = conv0 ? TH : (TH - 1) * st + ks, PW = conv0 ? TW : (TW - 1) * st + ks;
                 const size_t lds = conv_lds_bytes(ks, st, conv0 ? 1 : 0, TH, TW, WN, NREP);
-                if (lds > 80 * 1024) continue;
+                if (lds > ((fth || ftw) ? 160u : 80u) * 1024) continue;
                 // score: MFMA efficiency, mild preference for compact input patches (halo re-reads),
-                // for bigger per-wave register tiles (LDS traffic per MFMA ~ 1/NREP + 1/5) and for
-                // >= 2 workgroups per CU of LDS.
+                // for bigger per-wave register tiles (LDS traffic per MFMA ~ 1/NREP + 1/5), for long
+                // contiguous tile rows (coalescing) and for >= 2 workgroups per CU of LDS.
                 const double halo = (double)(TH * TW * st * st) / (PH * PW);
                 const double lds_traffic = 1.0 / NREP + 1.0 / 5;
-                // contiguous bytes per tile row (coalescing of the staging loads / epilogue stores)
                 const double rowb = std::min(1.0, (double)TW * 64.0 / 1024.0);
                 double score = m_eff * n_eff * (0.6 + 0.4 * halo) * (0.8 + 0.2 * rowb) / (0.35 + lds_traffic);
                 if (lds > 64 * 1024) score *= 0.9;
-                const double wgs = (double)tiles * gy * P.desc.max_batch;
+                const double wgs = (double)tiles * gy * max_batch;
                 if (wgs < 512) score *= 0.5 + 0.5 * wgs / 512;
                 if (score > best) {
                     best = score;
@@ -138,10 +140,7 @@ void choose_cfg(const Plan& P, Op& op) {
             }
         }
     }
-    (void)taps;
 }
-
-}  // namespace
 
 std::string Plan::build(const vti_desc& d) {
     desc = d;
@@ -261,17 +260,15 @@ std::string Plan::build(const vti_desc& d) {
     // launch geometry + packed-weight offsets
     macs = 0; fused_params = d.reg_max;
     size_t woff = 0, boff = 0;
-    const int VECB = 16;   // bytes per lane per fragment
     for (Op& op : ops) {
         if (op.kind != OP_CONV && op.kind != OP_CONV0) continue;
         const ConvRow& r = convs[op.conv];
         macs += r.macs(); fused_params += r.fused_params();
-        choose_cfg(*this, op);
+        choose_conv_cfg(d.dtype, r, op.kind == OP_CONV0, d.max_batch, op.cfg);
         if (op.cfg.TH == 0) return "no launch configuration for conv " + r.name;
-        const int taps = (op.kind == OP_CONV0) ? 1 : (r.kind == 2 ? 1 : r.k * r.k);
         op.cfg.wpk_off = woff;
         op.cfg.bias_off = boff;
-        woff += (size_t)op.cfg.nchunks * op.cfg.ntiles_n * taps * 64 * VECB;
+        woff += packed_conv_bytes(r, op.kind == OP_CONV0, op.cfg);
         boff += (size_t)op.cfg.ntiles_n * 16;
     }
     wpk_bytes = woff; bias_floats = boff;

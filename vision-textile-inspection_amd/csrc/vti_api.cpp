@@ -149,6 +149,28 @@ static void* buf_ptr(vti_ctx* c, int buf, const void* input, void* proto) {
     return c->ws + c->plan.bufs[buf].off;
 }
 
+// One conv launch's parameter block from its table row + geometry + tensor views.
+static void fill_conv_params(ConvParams& p, const ConvRow& r, const ConvCfg& g, int B, const void* in, int in_ld,
+                             int in_coff, void* out, int out_ld, int out_coff, const void* res, int res_ld,
+                             int res_coff, const void* wpk, const float* bias, bool out_f32, int swap_rb) {
+    const bool deconv = r.kind == 2;
+    memset(&p, 0, sizeof p);
+    p.in = in; p.out = out; p.wpk = wpk; p.bias = bias;
+    p.B = B; p.Hin = r.h_in; p.Win = r.w_in;
+    p.Hout = deconv ? r.h_in : r.h_out; p.Wout = deconv ? r.w_in : r.w_out;
+    p.Cin = r.c1; p.in_ld = in_ld; p.in_coff = in_coff;
+    p.Cout = g.gemm_n; p.out_ld = out_ld; p.out_coff = out_coff;
+    if (res) { p.res = res; p.res_ld = res_ld; p.res_coff = res_coff; p.has_res = 1; }
+    p.TH = g.TH; p.TW = g.TW;
+    p.tiles_y = (p.Hout + g.TH - 1) / g.TH; p.tiles_x = (p.Wout + g.TW - 1) / g.TW;
+    p.WN = g.WN;
+    p.act = r.kind == 0; p.out_f32 = out_f32 ? 1 : 0;
+    p.deconv_c = deconv ? r.c2 : 0;
+    p.swap_rb = swap_rb ? 1 : 0;
+    p.nchunks = g.nchunks; p.ntiles_n = g.ntiles_n;
+    p.scalar_store = (g.gemm_n % 4 || out_ld % 4 || out_coff % 4) ? 1 : 0;
+}
+
 int32_t vti_forward(vti_ctx* c, const uint8_t* input, int32_t B, int32_t swap_rb, float* pred, void* proto, void* stream) {
     int32_t rc = check_ready(c, B, "vti_forward");
     if (rc) return rc;
@@ -165,29 +187,13 @@ int32_t vti_forward(vti_ctx* c, const uint8_t* input, int32_t B, int32_t swap_rb
             const ConvCfg& g = op.cfg;
             const Buf& ib = P.bufs[op.in.buf];
             const Buf& ob = P.bufs[op.out.buf];
-            const bool deconv = r.kind == 2;
             ConvParams p;
-            memset(&p, 0, sizeof p);
-            p.in = buf_ptr(c, op.in.buf, input, proto);
-            p.out = buf_ptr(c, op.out.buf, input, proto);
-            p.wpk = (const char*)c->d_wpk + g.wpk_off;
-            p.bias = c->d_bias + g.bias_off;
-            p.B = B; p.Hin = ib.H; p.Win = ib.W;
-            p.Hout = deconv ? ib.H : r.h_out; p.Wout = deconv ? ib.W : r.w_out;
-            p.Cin = r.c1; p.in_ld = ib.C; p.in_coff = op.in.coff;
-            p.Cout = g.gemm_n; p.out_ld = ob.C; p.out_coff = op.out.coff;
-            if (op.has_res) {
-                p.res = buf_ptr(c, op.res.buf, input, proto);
-                p.res_ld = P.bufs[op.res.buf].C; p.res_coff = op.res.coff; p.has_res = 1;
-            }
-            p.TH = g.TH; p.TW = g.TW;
-            p.tiles_y = (p.Hout + g.TH - 1) / g.TH; p.tiles_x = (p.Wout + g.TW - 1) / g.TW;
-            p.WN = g.WN;
-            p.act = r.kind == 0; p.out_f32 = op.out_f32 ? 1 : 0;
-            p.deconv_c = deconv ? r.c2 : 0;
-            p.swap_rb = swap_rb ? 1 : 0;
-            p.nchunks = g.nchunks; p.ntiles_n = g.ntiles_n;
-            p.scalar_store = (g.gemm_n % 4 || ob.C % 4 || op.out.coff % 4) ? 1 : 0;
+            fill_conv_params(p, r, g, B, buf_ptr(c, op.in.buf, input, proto), ib.C, op.in.coff,
+                             buf_ptr(c, op.out.buf, input, proto), ob.C, op.out.coff,
+                             op.has_res ? buf_ptr(c, op.res.buf, input, proto) : nullptr,
+                             op.has_res ? P.bufs[op.res.buf].C : 0, op.res.coff,
+                             (const char*)c->d_wpk + g.wpk_off, c->d_bias + g.bias_off, op.out_f32, swap_rb);
+            const bool deconv = r.kind == 2;
             const int ks = deconv ? 1 : r.k, s = deconv ? 1 : r.s;
             VTI_HIP(c, launch_conv(dt, ks, s, g.NREP, op.kind == OP_CONV0 ? 1 : 0, p, g.lds, st), r.name.c_str());
             break;
@@ -321,6 +327,62 @@ int32_t vti_debug_conv_output(vti_ctx* c, int32_t i, int32_t B, float* out, void
     if (!src) return fail(c, VTI_ERR_STATE, "vti_debug_conv_output: run vti_forward first");
     const int is_f32 = (b.elem == EL_F32) || (b.elem == EL_T && c->plan.desc.dtype == VTI_F32);
     VTI_HIP(c, launch_debug_nchw(is_f32, src, B, b.H, b.W, v.C, b.C, v.coff, out, (hipStream_t)stream), "debug copy");
+    return VTI_OK;
+}
+
+int32_t vti_debug_conv2d(int32_t dtype, const void* dev_in, int32_t B, int32_t H, int32_t W, int32_t in_ld, int32_t in_coff,
+                         int32_t c1, const float* host_w, const float* host_b, int32_t c2, int32_t k, int32_t s, int32_t kind,
+                         const void* dev_res, int32_t res_ld, int32_t res_coff, void* dev_out, int32_t out_ld, int32_t out_coff,
+                         int32_t out_f32, int32_t swap_rb, int32_t tile_h, int32_t tile_w, int32_t waves_n, int32_t nrep,
+                         int32_t iters, float* ms_out, int32_t* cfg_out, void* stream) {
+    if (!dev_in || !host_w || !host_b || !dev_out || B < 1 || H < 1 || W < 1 || c1 < 1 || c2 < 1 || iters < 1)
+        return fail(nullptr, VTI_ERR_ARG, "vti_debug_conv2d: bad argument");
+    if ((dtype != VTI_F16 && dtype != VTI_F32) || (kind < 0 || kind > 2))
+        return fail(nullptr, VTI_ERR_ARG, "vti_debug_conv2d: bad dtype/kind");
+    const bool conv0 = (c1 == 3);   // u8 HWC3 input, the stem conv
+    if (conv0 ? !(k == 3 && s == 2 && kind == 0) : (c1 % 16 != 0))
+        return fail(nullptr, VTI_ERR_ARG, "vti_debug_conv2d: c1 must be 3 (stem) or a multiple of 16");
+    if (!((k == 1 && s == 1) || (k == 3 && (s == 1 || s == 2)) || (kind == 2 && k == 2 && s == 2)))
+        return fail(nullptr, VTI_ERR_ARG, "vti_debug_conv2d: unsupported kernel/stride");
+    ConvRow r;
+    r.name = "debug"; r.c1 = c1; r.c2 = c2; r.k = k; r.s = s; r.kind = kind; r.h_in = H; r.w_in = W;
+    if (kind == 2) { r.h_out = 2 * H; r.w_out = 2 * W; }
+    else { r.h_out = (H + 2 * (k / 2) - k) / s + 1; r.w_out = (W + 2 * (k / 2) - k) / s + 1; }
+    ConvCfg g;
+    choose_conv_cfg(dtype, r, conv0, B, g, tile_h, tile_w, waves_n, nrep);
+    if (g.TH == 0) return fail(nullptr, VTI_ERR_ARG, "vti_debug_conv2d: no launch configuration fits");
+    if (cfg_out) { cfg_out[0] = g.TH; cfg_out[1] = g.TW; cfg_out[2] = g.WN; cfg_out[3] = g.NREP; cfg_out[4] = (int32_t)g.lds; }
+    std::vector<uint8_t> wpk(packed_conv_bytes(r, conv0, g));
+    std::vector<float> bias((size_t)g.ntiles_n * 16);
+    pack_conv(dtype, r, conv0, g, host_w, host_b, wpk.data(), bias.data());
+    void* d_w = nullptr; float* d_b = nullptr;
+    hipStream_t st = (hipStream_t)stream;
+    VTI_HIP(nullptr, hipMalloc(&d_w, wpk.size()), "hipMalloc");
+    hipError_t e = hipMalloc((void**)&d_b, bias.size() * 4);
+    if (e == hipSuccess) e = hipMemcpy(d_w, wpk.data(), wpk.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_b, bias.data(), bias.size() * 4, hipMemcpyHostToDevice);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (e == hipSuccess) e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    if (e == hipSuccess) {
+        ConvParams p;
+        fill_conv_params(p, r, g, B, dev_in, in_ld, in_coff, dev_out, out_ld, out_coff, dev_res, res_ld, res_coff, d_w, d_b,
+                         out_f32 != 0, swap_rb);
+        const int ks = kind == 2 ? 1 : k, ss = kind == 2 ? 1 : s;
+        e = launch_conv(dtype, ks, ss, g.NREP, conv0 ? 1 : 0, p, g.lds, st);   // warm-up / the checked run
+        if (e == hipSuccess) e = hipEventRecord(e0, st);
+        for (int i = 1; i < iters && e == hipSuccess; ++i) e = launch_conv(dtype, ks, ss, g.NREP, conv0 ? 1 : 0, p, g.lds, st);
+        if (e == hipSuccess) e = hipEventRecord(e1, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        float ms = 0.f;
+        if (e == hipSuccess && iters > 1) e = hipEventElapsedTime(&ms, e0, e1);
+        if (ms_out) *ms_out = iters > 1 ? ms / (iters - 1) : 0.f;
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipFree(d_w);
+    if (d_b) (void)hipFree(d_b);
+    if (e != hipSuccess) return hip_fail(nullptr, e, "vti_debug_conv2d");
     return VTI_OK;
 }
 

@@ -128,6 +128,13 @@ hipError_t launch_union_envelope(const uint8_t* bitmaps, const int* select, int 
                                  uint8_t* uni, int* envelope, hipStream_t st);
 hipError_t launch_mask_stats(const uint8_t* bitmaps, int n, int H0, int W0, long long* stats, hipStream_t st);
 
+// plan.cpp: launch geometry for one conv (tile, wave split, LDS) -- th/tw/wn/nrep > 0 force a choice
+void choose_conv_cfg(int dtype, const ConvRow& r, bool conv0, int max_batch, ConvCfg& c,
+                     int th = 0, int tw = 0, int wn = 0, int nrep = 0);
+// weights.cpp: one conv's weights -> fragment order; dst_w has cfg.nchunks*ntiles_n*taps KiB, dst_b ntiles_n*16 floats
+void pack_conv(int dtype, const ConvRow& r, bool conv0, const ConvCfg& c, const float* w, const float* b,
+               uint8_t* dst_w, float* dst_b);
+size_t packed_conv_bytes(const ConvRow& r, bool conv0, const ConvCfg& c);
 // weights.cpp: parse VTIW1 + pack into MFMA fragment order (host memory)
 std::string pack_weights(const Plan& plan, const void* blob, size_t nbytes,
                          std::vector<uint8_t>& wpk, std::vector<float>& bias);

@@ -21,6 +21,47 @@ struct Rec { char name[48]; uint32_t c1, c2, k, s, kind; char pad[12]; };
 static_assert(sizeof(Hdr) == 64 && sizeof(Rec) == 80, "VTIW1 record sizes");
 }  // namespace
 
+size_t packed_conv_bytes(const ConvRow& r, bool conv0, const ConvCfg& c) {
+    const int taps = (conv0 || r.kind == 2) ? 1 : r.k * r.k;
+    return (size_t)c.nchunks * c.ntiles_n * taps * 64 * 16;
+}
+
+void pack_conv(int dtype, const ConvRow& r, bool conv0, const ConvCfg& c, const float* w, const float* b,
+               uint8_t* dst, float* bd) {
+    const bool f16 = dtype == VTI_F16;
+    const int KC = f16 ? 32 : 16, VEC = f16 ? 8 : 4;
+    const bool deconv = r.kind == 2;
+    const int taps = (conv0 || deconv) ? 1 : r.k * r.k;
+    for (int ck = 0; ck < c.nchunks; ++ck)
+        for (int nt = 0; nt < c.ntiles_n; ++nt)
+            for (int tap = 0; tap < taps; ++tap)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < VEC; ++j) {
+                        const int ng = nt * 16 + (lane & 15);
+                        const int kk = ck * KC + (lane >> 4) * VEC + j;
+                        float v = 0.f;
+                        if (ng < c.gemm_n) {
+                            if (conv0) {
+                                if (kk < 27) {   // k = (kh*3+kw)*3 + channel
+                                    const int t = kk / 3, chn = kk % 3;
+                                    v = w[((size_t)ng * 3 + chn) * 9 + t];
+                                }
+                            } else if (deconv) {
+                                if (kk < r.c1) {   // gemm column = (dy*2+dx)*c2 + co ; torch IOHW
+                                    const int q = ng / r.c2, co = ng % r.c2;
+                                    v = w[((size_t)kk * r.c2 + co) * 4 + q];
+                                }
+                            } else if (kk < r.c1) {
+                                v = w[((size_t)ng * r.c1 + kk) * taps + tap];
+                            }
+                        }
+                        const size_t e = ((((size_t)ck * c.ntiles_n + nt) * taps + tap) * 64 + lane) * VEC + j;
+                        if (f16) ((_Float16*)dst)[e] = (_Float16)v;
+                        else ((float*)dst)[e] = v;
+                    }
+    for (int n = 0; n < c.ntiles_n * 16; ++n) bd[n] = n < c.gemm_n ? b[deconv ? n % r.c2 : n] : 0.f;
+}
+
 std::string pack_weights(const Plan& plan, const void* blob, size_t nbytes, std::vector<uint8_t>& wpk,
                          std::vector<float>& bias) {
     const uint8_t* p = (const uint8_t*)blob;
@@ -33,8 +74,6 @@ std::string pack_weights(const Plan& plan, const void* blob, size_t nbytes, std:
         return "weights: container scale/nc/nm/reg_max do not match the model description";
     if (h.n_convs != plan.convs.size()) return "weights: conv count does not match the plan";
 
-    const bool f16 = plan.desc.dtype == VTI_F16;
-    const int KC = f16 ? 32 : 16, VEC = f16 ? 8 : 4;
     wpk.assign(plan.wpk_bytes, 0);
     bias.assign(plan.bias_floats, 0.f);
 
@@ -62,39 +101,8 @@ std::string pack_weights(const Plan& plan, const void* blob, size_t nbytes, std:
         memcpy(b.data(), p + off, 4 * (size_t)r.c2); off += 4 * (size_t)r.c2;
 
         const Op& op = *op_of[i];
-        const ConvCfg& c = op.cfg;
-        const bool conv0 = op.kind == OP_CONV0, deconv = r.kind == 2;
-        const int taps = (conv0 || deconv) ? 1 : r.k * r.k;
-        uint8_t* dst = wpk.data() + c.wpk_off;
-        for (int ck = 0; ck < c.nchunks; ++ck)
-            for (int nt = 0; nt < c.ntiles_n; ++nt)
-                for (int tap = 0; tap < taps; ++tap)
-                    for (int lane = 0; lane < 64; ++lane)
-                        for (int j = 0; j < VEC; ++j) {
-                            const int ng = nt * 16 + (lane & 15);
-                            const int kk = ck * KC + (lane >> 4) * VEC + j;
-                            float v = 0.f;
-                            if (ng < c.gemm_n) {
-                                if (conv0) {
-                                    if (kk < 27) {   // k = (kh*3+kw)*3 + channel
-                                        const int t = kk / 3, chn = kk % 3;
-                                        v = w[((size_t)ng * 3 + chn) * 9 + t];
-                                    }
-                                } else if (deconv) {
-                                    if (kk < r.c1) {   // gemm column = (dy*2+dx)*c2 + co ; torch IOHW
-                                        const int q = ng / r.c2, co = ng % r.c2;
-                                        v = w[((size_t)kk * r.c2 + co) * 4 + q];
-                                    }
-                                } else if (kk < r.c1) {
-                                    v = w[((size_t)ng * r.c1 + kk) * taps + tap];
-                                }
-                            }
-                            const size_t e = ((((size_t)ck * c.ntiles_n + nt) * taps + tap) * 64 + lane) * VEC + j;
-                            if (f16) ((_Float16*)dst)[e] = (_Float16)v;
-                            else ((float*)dst)[e] = v;
-                        }
-        float* bd = bias.data() + c.bias_off;
-        for (int n = 0; n < c.gemm_n; ++n) bd[n] = b[deconv ? n % r.c2 : n];
+        pack_conv(plan.desc.dtype, r, op.kind == OP_CONV0, op.cfg, w.data(), b.data(), wpk.data() + op.cfg.wpk_off,
+                  bias.data() + op.cfg.bias_off);
     }
     if (off != nbytes) return "weights: trailing bytes in container";
     return "";

@@ -231,3 +231,32 @@ def unpack_bits(bits, W):
 
 def to_numpy(t):
     return t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
+
+
+def debug_conv2d(x, w, b, k, s, kind=0, dtype="fp16", res=None, out=None, in_coff=0, c1=None, out_coff=0, out_ld=None,
+                 out_f32=False, swap_rb=False, tile=(0, 0), waves_n=0, nrep=0, iters=1):
+    """Run ONE conv of the engine's conv family (vti_debug_conv2d): unit tests / micro-benchmarks.
+    x: device tensor NHWC [B,H,W,ld] of the engine dtype (or uint8 [B,H,W,3] for the stem);
+    w: f32 OIHW (kind 2: IOHW) numpy/torch on host; returns (out NHWC, ms_per_launch, cfg)."""
+    B, H, W, ld = x.shape
+    w = np.ascontiguousarray(to_numpy(w), dtype=np.float32)
+    b = np.ascontiguousarray(to_numpy(b), dtype=np.float32)
+    c2 = w.shape[1] if kind == 2 else w.shape[0]
+    if c1 is None:
+        c1 = w.shape[0] if kind == 2 else w.shape[1]
+    Ho, Wo = (2 * H, 2 * W) if kind == 2 else ((H + 2 * (k // 2) - k) // s + 1, (W + 2 * (k // 2) - k) // s + 1)
+    tdt = torch.float32 if (out_f32 or DTYPES[dtype] == _lib.VTI_F32) else torch.float16
+    if out is None:
+        out_ld = out_ld or (out_coff + c2)
+        out = torch.zeros((B, Ho, Wo, out_ld), dtype=tdt, device=x.device)
+    else:
+        out_ld = out.shape[3]
+    ms = C.c_float(0)
+    cfg = (C.c_int32 * 5)()
+    rc = lib().vti_debug_conv2d(DTYPES[dtype], _ptr(x), B, H, W, ld, in_coff, c1, w.ctypes.data_as(C.c_void_p),
+                                b.ctypes.data_as(C.c_void_p), c2, k, s, kind, _ptr(res), res.shape[3] if res is not None else 0,
+                                0, _ptr(out), out_ld, out_coff, int(out_f32), int(swap_rb), tile[0], tile[1], waves_n, nrep,
+                                iters, C.byref(ms), cfg, _stream())
+    if rc != 0:
+        raise _lib.VtiError(rc, lib().vti_last_error(None).decode())
+    return out, ms.value, dict(tile=(cfg[0], cfg[1]), waves_n=cfg[2], nrep=cfg[3], lds=cfg[4])
