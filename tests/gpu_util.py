@@ -13,11 +13,11 @@ def need_gpu():
 
 
 @functools.lru_cache(maxsize=8)
-def engine_and_oracle(scale, nc, H, W, B, dtype, seed=1, cls_bias=None):
+def engine_and_oracle(scale, nc, H, W, B, dtype, seed=1, cls_bias=None, gain=1.7):
     import vti_amd
     from oracle.model import OracleModel
     eng = vti_amd.Engine(scale, nc, H=H, W=W, max_batch=B, dtype=dtype)
-    blob = vti_amd.random_weights(eng, seed=seed, cls_bias=cls_bias)
+    blob = vti_amd.random_weights(eng, seed=seed, cls_bias=cls_bias, gain=gain)
     eng.load_weights(blob, 0)
     return eng, OracleModel(blob, H, W, mode=dtype), blob
 

@@ -35,6 +35,8 @@ def pack_container(scale, nc, nm, reg_max, table, tensors):
 
 def unpack_container(blob):
     mv = memoryview(blob)
+    if len(mv) < _HDR.size:
+        raise ValueError("not a VTIW1 container (too short)")
     magic, ver, scale, nc, nm, reg_max, n = _HDR.unpack_from(mv, 0)
     if magic != MAGIC or ver != 1:
         raise ValueError("not a VTIW1 container")
