@@ -45,9 +45,30 @@ __device__ __forceinline__ f32x4 mma(f32x4 w, f32x4 x, f32x4 c) {
     return c;
 }
 
-__device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }
+// SiLU.  fp32 engine (parity mode): IEEE exp + division, as the CPU reference computes it.
+// fp16 engine: v_exp_f32 + v_rcp_f32 (each ~1 ulp in f32, far below the fp16 rounding that follows);
+// the accurate form costs ~30 VALU instructions per element and dominated the kernel's issue slots.
+template <bool FAST> __device__ __forceinline__ float silu(float x) {
+    if constexpr (FAST) return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
+    else return x / (1.0f + expf(-x));
+}
 
 constexpr int MREP = 5;
+
+// Diagnostic build (make STAMPS=1 -> libvti_stamps.so, used only by tools/): s_memtime stamps of
+// workgroup phases, written by wave 0 to a buffer nothing else reads.  Compiled out of the product.
+#ifdef VTI_STAMPS
+#define VTI_STAMP(i)                                                                              \
+    do {                                                                                          \
+        if (p.stamps && tid == 0) {                                                               \
+            unsigned long long t_;                                                                \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");            \
+            p.stamps[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 + (i)] = t_;              \
+        }                                                                                         \
+    } while (0)
+#else
+#define VTI_STAMP(i) do { } while (0)
+#endif
 
 __host__ __device__ inline int patch_dim(int t, int ks, int s, int mode) { return mode == 1 ? t : (t - 1) * s + ks; }
 
@@ -55,15 +76,22 @@ size_t conv_lds_bytes(int ks, int stride, int mode, int TH, int TW, int WN, int 
     const int npix = patch_dim(TH, ks, stride, mode) * patch_dim(TW, ks, stride, mode);
     const size_t plane = (size_t)((npix + 15) & ~15) * 16;
     const int taps = mode == 1 ? 1 : ks * ks;
-    return 4 * plane + (size_t)WN * NREP * taps * 1024;
+    size_t raw = 0;
+    if (mode == 1) raw = (((size_t)(2 * TH + 1) * (2 * TW + 1) * 3) + 15) & ~(size_t)15;   // u8 input patch
+    return 4 * plane + (size_t)WN * NREP * taps * 1024 + raw;
 }
 
+// Register-staged operand prefetch: a thread owns up to AR input-patch pieces and BR weight pieces
+// (16 B each) of a chunk.  issue() only starts the global loads; commit() writes them to LDS.  The
+// next chunk is issued before the MFMA loop of the current one, so HBM/L2 latency hides under MFMA.
 template <typename T, int KS, int S, int NREP, int MODE>
 __global__ __launch_bounds__(256) void conv_kernel(const ConvParams p) {
     using vec = typename Tr<T>::vec;
     constexpr int VEC = Tr<T>::VEC, KC = Tr<T>::KC;
     constexpr int TAPS = (MODE == 1) ? 1 : KS * KS;
     constexpr int PAD = KS / 2;
+    constexpr int AR = (MODE == 1) ? 1 : (S == 2 ? 12 : 8);
+    constexpr int BR = (TAPS == 1) ? 5 : 12;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -82,6 +110,7 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvParams p) {
     const int NTB = WN * NREP;
     const int nt0 = blockIdx.y * NTB;
     const int tile_px = p.TH * p.TW;
+    VTI_STAMP(0);
 
     // per-lane pixel bookkeeping for the MREP pixel tiles of this wave
     int abase[MREP], opy[MREP], opx[MREP];
@@ -91,7 +120,7 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvParams p) {
         const int pp = (wm * MREP + m) * 16 + (lane & 15);
         const bool v = pp < tile_px;
         const int pc = v ? pp : 0;
-        const int py = pc / p.TW, px = pc - py * p.TW;
+        const int py = (int)__umulhi((unsigned)pc, p.tw_magic), px = pc - py * p.TW;
         opy[m] = oy0 + py; opx[m] = ox0 + px;
         pvalid[m] = v && opy[m] < p.Hout && opx[m] < p.Wout;
         const int lpix = (MODE == 1) ? pc : (py * S) * PW + px * S;
@@ -105,31 +134,59 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvParams p) {
         for (int n = 0; n < NREP; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int iy0 = oy0 * S - PAD, ix0 = ox0 * S - PAD;
+    const int nitemA = npix * 4;
+    int ntv = p.ntiles_n - nt0;
+    ntv = ntv < NTB ? ntv : NTB;
+    const int nvalidB = ntv * TAPS * 64, ntotB = NTB * TAPS * 64;
 
-    for (int c = 0; c < p.nchunks; ++c) {
-        if (c) __syncthreads();
-        // ---- stage the input patch: plane q <- channels [c*KC + q*VEC, +VEC) of every patch pixel
+    // per-thread source offsets of the A pieces are chunk-invariant: compute them once
+    // (element offset of the piece's first channel in chunk 0, or -1 for zero fill)
+    long aoff[AR];
+    if constexpr (MODE == 0) {
+#pragma unroll
+        for (int u = 0; u < AR; ++u) {
+            const int i = tid + u * 256;
+            const int pix = i >> 2, q = i & 3;
+            const int py = (int)__umulhi((unsigned)pix, p.pw_magic), px = pix - py * PW;
+            const int y = iy0 + py, x = ix0 + px;
+            const bool ok = i < nitemA && (unsigned)y < (unsigned)p.Hin && (unsigned)x < (unsigned)p.Win;
+            aoff[u] = ok ? (long)(((size_t)(b * p.Hin + y) * p.Win + x) * p.in_ld + p.in_coff + q * VEC) : -1;
+        }
+    }
+    vec ra[AR], rb[BR];
+    auto issue = [&](int c) {
         if constexpr (MODE == 0) {
             const T* inb = (const T*)p.in;
-            for (int i = tid; i < npix * 4; i += 256) {
-                const int pix = i >> 2, q = i & 3;
-                const int py = pix / PW, px = pix - py * PW;
-                const int y = iy0 + py, x = ix0 + px;
-                const int ch = c * KC + q * VEC;
-                vec v;
 #pragma unroll
-                for (int j = 0; j < VEC; ++j) v[j] = 0;
-                if ((unsigned)y < (unsigned)p.Hin && (unsigned)x < (unsigned)p.Win && ch < p.Cin)
-                    v = *(const vec*)(inb + ((size_t)(b * p.Hin + y) * p.Win + x) * p.in_ld + p.in_coff + ch);
-                *(vec*)(smA + q * plane_bytes + pix * 16) = v;
+            for (int u = 0; u < AR; ++u) {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) ra[u][j] = 0;
+                if (aoff[u] >= 0 && c * KC + (tid & 3) * VEC < p.Cin) ra[u] = *(const vec*)(inb + aoff[u] + c * KC);
+            }
+        }
+        const vec* wsrc = (const vec*)p.wpk + ((size_t)c * p.ntiles_n + nt0) * (TAPS * 64);
+#pragma unroll
+        for (int u = 0; u < BR; ++u) {
+            const int i = tid + u * 256;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) rb[u][j] = 0;
+            if (i < nvalidB) rb[u] = wsrc[i];
+        }
+    };
+    auto commit = [&](int c) {
+        if constexpr (MODE == 0) {
+#pragma unroll
+            for (int u = 0; u < AR; ++u) {
+                const int i = tid + u * 256;
+                if (i < nitemA) *(vec*)(smA + (i & 3) * plane_bytes + (i >> 2) * 16) = ra[u];
             }
         } else {
-            // conv0: u8 HWC3 frame, im2col on the fly: k = (kh*3+kw)*3 + channel, K = 27 padded to 32
-            const uint8_t* inb = (const uint8_t*)p.in;
-            for (int i = tid; i < npix * 4; i += 256) {
+            // conv0: im2col from the u8 patch staged in LDS: k = (kh*3+kw)*3 + channel, K = 27 -> 32
+            const int RWB = (2 * p.TW + 1) * 3;
+            const unsigned char* raw = (const unsigned char*)(smB + NTB * TAPS * 1024);
+            for (int i = tid; i < nitemA; i += 256) {
                 const int pix = i >> 2, q = i & 3;
-                const int py = pix / PW, px = pix - py * PW;
-                const int oy = oy0 + py, ox = ox0 + px;
+                const int py = (int)__umulhi((unsigned)pix, p.pw_magic), px = pix - py * PW;
                 vec v;
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) {
@@ -138,32 +195,47 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvParams p) {
                     if (k < 27) {
                         const int tap = k / 3, chn = k - tap * 3;
                         const int kh = tap / 3, kw = tap - kh * 3;
-                        const int y = oy * 2 - 1 + kh, x = ox * 2 - 1 + kw;
-                        if ((unsigned)y < (unsigned)p.Hin && (unsigned)x < (unsigned)p.Win) {
-                            const int cs = p.swap_rb ? 2 - chn : chn;
-                            f = (float)inb[((size_t)(b * p.Hin + y) * p.Win + x) * 3 + cs] / 255.0f;
-                        }
+                        const int cs = p.swap_rb ? 2 - chn : chn;
+                        // zero padding: out-of-image bytes were staged as 0 and 0/255 == 0
+                        f = (float)raw[(py * 2 + kh) * RWB + (px * 2 + kw) * 3 + cs] / 255.0f;
                     }
                     v[j] = (T)f;
                 }
                 *(vec*)(smA + q * plane_bytes + pix * 16) = v;
             }
         }
-        // ---- stage this chunk's weight fragments (contiguous in the packed image)
-        {
-            const vec* wsrc = (const vec*)p.wpk + ((size_t)c * p.ntiles_n + nt0) * (TAPS * 64);
-            int ntv = p.ntiles_n - nt0;
-            ntv = ntv < NTB ? ntv : NTB;
-            const int nvalid = ntv * TAPS * 64;
-            for (int i = tid; i < NTB * TAPS * 64; i += 256) {
-                vec v;
 #pragma unroll
-                for (int j = 0; j < VEC; ++j) v[j] = 0;
-                if (i < nvalid) v = wsrc[i];
-                ((vec*)smB)[i] = v;
-            }
+        for (int u = 0; u < BR; ++u) {
+            const int i = tid + u * 256;
+            if (i < ntotB) ((vec*)smB)[i] = rb[u];
+        }
+    };
+
+    if constexpr (MODE == 1) {
+        // u8 frame patch (2*TH+1 x 2*TW+1 x 3 bytes) -> LDS with coalesced loads, zero outside the image
+        const uint8_t* inb = (const uint8_t*)p.in;
+        const int RH = 2 * p.TH + 1, RWB = (2 * p.TW + 1) * 3;
+        unsigned char* raw = (unsigned char*)(smB + NTB * TAPS * 1024);
+        const int y0 = oy0 * 2 - 1, x0b = (ox0 * 2 - 1) * 3;
+        for (int i = tid; i < RH * RWB; i += 256) {
+            const int ry = (int)__umulhi((unsigned)i, p.rw_magic), rx = i - ry * RWB;
+            const int y = y0 + ry, xb = x0b + rx;
+            unsigned char val = 0;
+            if ((unsigned)y < (unsigned)p.Hin && (unsigned)xb < (unsigned)(p.Win * 3))
+                val = inb[((size_t)(b * p.Hin + y) * p.Win) * 3 + xb];
+            raw[i] = val;
         }
         __syncthreads();
+    }
+
+    issue(0);
+    for (int c = 0; c < p.nchunks; ++c) {
+        if (c < 2) VTI_STAMP(1 + 5 * c);
+        commit(c);                          // waits for this chunk's loads, fills LDS
+        if (c < 2) VTI_STAMP(3 + 5 * c);
+        __syncthreads();
+        if (c < 2) VTI_STAMP(4 + 5 * c);
+        if (c + 1 < p.nchunks) issue(c + 1);   // in flight during the MFMA loop below
         // ---- MFMA over the taps of this chunk
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) {
@@ -179,22 +251,82 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvParams p) {
                 for (int n = 0; n < NREP; ++n) acc[m][n] = mma(w[n], x, acc[m][n]);
             }
         }
+        if (c < 2) VTI_STAMP(5 + 5 * c);
+        if (c + 1 < p.nchunks) __syncthreads();   // everyone is done reading LDS before it is refilled
     }
 
-    // ---- epilogue: bias, SiLU, residual, store 4 consecutive channels per lane
+    VTI_STAMP(11);
+    // ---- epilogue: bias, SiLU, residual, store 4 consecutive channels per lane.
+    // Bias (and the residual of a whole pixel row) are loaded up front: a load inside the store loop
+    // would make every block wait on vmcnt(0), i.e. on all earlier STORES as well.
+    constexpr bool FAST = sizeof(T) == 2;
+    f32x4 bias_r[NREP];
+    int cout_r[NREP];
+#pragma unroll
+    for (int n = 0; n < NREP; ++n) {
+        cout_r[n] = (nt0 + wn * NREP + n) * 16 + (lane >> 4) * 4;
+        const int cb = cout_r[n] < p.ntiles_n * 16 ? cout_r[n] : 0;     // bias is padded to 16 floats per n-tile
+        bias_r[n] = *(const f32x4*)(p.bias + cb);
+    }
+    if (!p.scalar_store && !p.out_f32 && !p.deconv_c) {
+        // common case: T output, vector stores, plain NHWC addressing -- no per-element branches
+        const bool has_res = __builtin_amdgcn_readfirstlane(p.has_res) != 0;
+#pragma unroll
+        for (int m = 0; m < MREP; ++m) {
+            if (!pvalid[m]) continue;
+            const size_t opix = ((size_t)(b * p.Hout + opy[m])) * p.Wout + opx[m];
+            T* op = (T*)p.out + opix * p.out_ld + p.out_coff;
+            f32x4 res_r[NREP];
+            if (has_res) {
+                const T* rp = (const T*)p.res + opix * p.res_ld + p.res_coff;
+#pragma unroll
+                for (int n = 0; n < NREP; ++n) {
+                    res_r[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if (cout_r[n] < p.Cout) {
+                        if constexpr (sizeof(T) == 2) {
+                            const half4 r = *(const half4*)(rp + cout_r[n]);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) res_r[n][j] = (float)r[j];
+                        } else {
+                            res_r[n] = *(const f32x4*)(rp + cout_r[n]);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int n = 0; n < NREP; ++n) {
+                if (cout_r[n] >= p.Cout) continue;
+                f32x4 v = acc[m][n] + bias_r[n];
+                if (p.act) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = silu<FAST>(v[j]);
+                }
+                if (has_res) v += res_r[n];
+                if constexpr (sizeof(T) == 2) {
+                    half4 hv;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) hv[j] = (half_t)v[j];
+                    *(half4*)(op + cout_r[n]) = hv;
+                } else {
+                    *(f32x4*)(op + cout_r[n]) = v;
+                }
+            }
+        }
+        VTI_STAMP(12);
+        return;
+    }
+    // general case: fp32 head outputs, ragged channel counts (scalar stores), ConvTranspose scatter
 #pragma unroll
     for (int m = 0; m < MREP; ++m) {
         if (!pvalid[m]) continue;
 #pragma unroll
         for (int n = 0; n < NREP; ++n) {
-            const int cout0 = (nt0 + wn * NREP + n) * 16 + (lane >> 4) * 4;
+            const int cout0 = cout_r[n];
             if (cout0 >= p.Cout) continue;
-            f32x4 v = acc[m][n];
-            const f32x4 bb = *(const f32x4*)(p.bias + cout0);   // bias is padded to 16 floats per n-tile
-            v += bb;
+            f32x4 v = acc[m][n] + bias_r[n];
             if (p.act) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = silu(v[j]);
+                for (int j = 0; j < 4; ++j) v[j] = silu<FAST>(v[j]);
             }
             size_t opix;
             int co = cout0;
@@ -234,6 +366,16 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvParams p) {
             }
         }
     }
+    VTI_STAMP(12);
+}
+
+// Host-side check that a geometry fits the kernel's fixed register staging arrays.
+bool conv_cfg_fits(int ks, int stride, int mode, int TH, int TW, int WN, int NREP) {
+    const int taps = mode == 1 ? 1 : ks * ks;
+    const int AR = mode == 1 ? 1 : (stride == 2 ? 12 : 8), BR = taps == 1 ? 5 : 12;
+    const int npix = patch_dim(TH, ks, stride, mode) * patch_dim(TW, ks, stride, mode);
+    if (mode == 0 && npix * 4 > 256 * AR) return false;
+    return WN * NREP * taps * 64 <= 256 * BR;
 }
 
 template <typename T, int KS, int S, int MODE>
@@ -241,9 +383,11 @@ static hipError_t launch_nrep(int nrep, const ConvParams& p, dim3 grid, size_t l
 #define VTI_LAUNCH(N)                                                                         \
     case N: {                                                                                 \
         auto k = conv_kernel<T, KS, S, N, MODE>;                                              \
-        if (lds > 64 * 1024) {                                                                \
-            hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        static size_t lds_ok = 64 * 1024;                                                     \
+        if (lds > lds_ok) {                                                                   \
+            hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
             if (e != hipSuccess) return e;                                                    \
+            lds_ok = 160 * 1024;                                                              \
         }                                                                                     \
         hipLaunchKernelGGL(k, grid, dim3(256), lds, st, p);                                   \
         return hipGetLastError();                                                             \

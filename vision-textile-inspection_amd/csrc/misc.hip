@@ -56,9 +56,65 @@ __global__ __launch_bounds__(256) void sppf_pool_kernel(const PoolParams p) {
     }
 }
 
+// Fast path: one workgroup per (frame, 16-B channel group); the whole H x W map of that group sits in
+// LDS and the three chained 5x5 pools run as separable row/column passes -- exactly the reference's
+// chained MaxPool2d(5,1,2) (max is exact, so fp16/fp32 results are bit-identical to the chained form).
+template <typename T>
+__global__ __launch_bounds__(256) void sppf_pool_lds_kernel(const PoolParams p) {
+    using vec = typename V16<T>::vec;
+    constexpr int N = V16<T>::N;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int HW = p.H * p.W;
+    vec* cur = (vec*)smem;              // [HW]
+    vec* tmp = cur + HW;                // [HW]
+    const int cv = p.C / N;
+    const int b = blockIdx.x / cv, c = blockIdx.x - b * cv;
+    const T* in = (const T*)p.in + (size_t)b * HW * p.ld + p.in_coff + c * N;
+    T* out = (T*)p.out + (size_t)b * HW * p.ld + p.out_coff + c * N;
+    for (int i = threadIdx.x; i < HW; i += 256) cur[i] = *(const vec*)(in + (size_t)i * p.ld);
+    __syncthreads();
+    for (int pass = 0; pass < 3; ++pass) {
+        for (int i = threadIdx.x; i < HW; i += 256) {       // row pass: max over x-2..x+2
+            const int y = i / p.W, x = i - y * p.W;
+            vec m = cur[i];
+            for (int d = -2; d <= 2; ++d) {
+                const int xx = x + d;
+                if (d == 0 || (unsigned)xx >= (unsigned)p.W) continue;
+                const vec v = cur[y * p.W + xx];
+#pragma unroll
+                for (int j = 0; j < N; ++j) m[j] = v[j] > m[j] ? v[j] : m[j];
+            }
+            tmp[i] = m;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < HW; i += 256) {       // column pass + store this pool level
+            const int y = i / p.W, x = i - y * p.W;
+            vec m = tmp[i];
+            for (int d = -2; d <= 2; ++d) {
+                const int yy = y + d;
+                if (d == 0 || (unsigned)yy >= (unsigned)p.H) continue;
+                const vec v = tmp[yy * p.W + x];
+#pragma unroll
+                for (int j = 0; j < N; ++j) m[j] = v[j] > m[j] ? v[j] : m[j];
+            }
+            cur[i] = m;
+            *(vec*)(out + (size_t)i * p.ld + pass * p.C) = m;
+        }
+        __syncthreads();
+    }
+}
+
 hipError_t launch_sppf_pool(int dtype, const PoolParams& p, hipStream_t st) {
-    const long total = (long)p.B * p.H * p.W * (p.C / (dtype == VTI_F16 ? 8 : 4));
+    const int N = dtype == VTI_F16 ? 8 : 4;
+    const long total = (long)p.B * p.H * p.W * (p.C / N);
     if (total == 0) return hipSuccess;
+    const size_t lds = (size_t)2 * p.H * p.W * 16;
+    if (lds <= 64 * 1024) {
+        const int grid = p.B * (p.C / N);
+        if (dtype == VTI_F16) hipLaunchKernelGGL(sppf_pool_lds_kernel<half_t>, dim3(grid), dim3(256), lds, st, p);
+        else hipLaunchKernelGGL(sppf_pool_lds_kernel<float>, dim3(grid), dim3(256), lds, st, p);
+        return hipGetLastError();
+    }
     const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     if (dtype == VTI_F16) hipLaunchKernelGGL(sppf_pool_kernel<half_t>, dim3(grid), dim3(256), 0, st, p);
     else hipLaunchKernelGGL(sppf_pool_kernel<float>, dim3(grid), dim3(256), 0, st, p);
@@ -97,53 +153,82 @@ hipError_t launch_upsample2x(int dtype, const Up2Params& p, hipStream_t st) {
 //   DFL: softmax over reg_max bins per side, expectation with arange weights -> l,t,r,b
 //   dist2bbox(xywh=True): x1y1 = anchor - lt, x2y2 = anchor + rb, (cxcy, wh) * stride
 //   class scores -> sigmoid; mask coefficients copied.
-// One thread per (frame, anchor); stores are coalesced along the anchor axis of pred [B,no,A].
-__global__ __launch_bounds__(256) void decode_kernel(const DecodeParams p) {
-    const long total = (long)p.B * p.A;
-    const long i = blockIdx.x * 256L + threadIdx.x;
-    if (i >= total) return;
-    const int a = (int)(i % p.A);
-    const int b = (int)(i / p.A);
-    int l = 0;
-    if (a >= p.a0[2]) l = 2; else if (a >= p.a0[1]) l = 1;
-    const int la = a - p.a0[l];
-    const int W = p.W[l], HW = p.H[l] * W;
-    const int gy = la / W, gx = la - gy * W;
-    const size_t pix = (size_t)b * HW + la;
-    const int no = 4 + p.nc + p.nm;
-    float* out = p.pred + (size_t)b * no * p.A + a;
+// One workgroup per (frame, 64 consecutive anchors of one level).  The anchors' rows of the three
+// head tensors ([anchor][64 | nc | nm], anchor-major) are contiguous, so they are loaded with
+// coalesced dwords into an LDS tile [64][no_in+1]; the channel-major pred [B,4+nc+nm,A] is then
+// written 64 anchors (256 B) at a time -- both sides of the transpose are coalesced.
+constexpr int DEC_TA = 64;
 
-    const float* bx = p.box[l] + pix * (4 * p.reg_max);
-    float dist[4];
-    for (int s = 0; s < 4; ++s) {
-        float v[16];
+__global__ __launch_bounds__(256) void decode_kernel(const DecodeParams p, int tiles0, int tiles1, int tiles_per_frame) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];
+    const int b = blockIdx.x / tiles_per_frame;
+    int t = blockIdx.x - b * tiles_per_frame;
+    int l = 0;
+    if (t >= tiles0 + tiles1) { l = 2; t -= tiles0 + tiles1; } else if (t >= tiles0) { l = 1; t -= tiles0; }
+    const int W = p.W[l], HW = p.H[l] * W;
+    const int la0 = t * DEC_TA;
+    const int na = min(DEC_TA, HW - la0);
+    const int nbox = 4 * p.reg_max, nin = nbox + p.nc + p.nm, pitch = nin + 1;
+    const int tid = threadIdx.x;
+    const size_t pix0 = (size_t)b * HW + la0;
+    // coalesced loads: each source is one contiguous run of na rows
+    const float* src = p.box[l] + pix0 * nbox;
+    for (int i = tid; i < na * nbox; i += 256) { const int a = i / nbox, k = i - a * nbox; tile[a * pitch + k] = src[i]; }
+    src = p.cls[l] + pix0 * p.nc;
+    for (int i = tid; i < na * p.nc; i += 256) { const int a = i / p.nc, k = i - a * p.nc; tile[a * pitch + nbox + k] = src[i]; }
+    src = p.mc[l] + pix0 * p.nm;
+    for (int i = tid; i < na * p.nm; i += 256) { const int a = i / p.nm, k = i - a * p.nm; tile[a * pitch + nbox + p.nc + k] = src[i]; }
+    __syncthreads();
+    // DFL expectation: thread = (anchor, side)
+    float dist = 0.f;
+    const int a_ = tid >> 2, side = tid & 3;
+    if (a_ < na) {
+        const float* v = tile + a_ * pitch + side * 16;
+        float e[16];
         float mx = -INFINITY;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) { v[k] = bx[s * 16 + k]; mx = fmaxf(mx, v[k]); }
-        float sum = 0.f, acc = 0.f;
+        for (int k = 0; k < 16; ++k) { e[k] = v[k]; mx = fmaxf(mx, e[k]); }
+        float sum = 0.f;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) { const float e = expf(v[k] - mx); sum += e; v[k] = e; }
+        for (int k = 0; k < 16; ++k) { e[k] = expf(e[k] - mx); sum += e[k]; }
 #pragma unroll
-        for (int k = 0; k < 16; ++k) acc += (v[k] / sum) * (float)k;
-        dist[s] = acc;
+        for (int k = 0; k < 16; ++k) dist += (e[k] / sum) * (float)k;
     }
-    const float ax = (float)gx + 0.5f, ay = (float)gy + 0.5f;
-    const float x1 = ax - dist[0], y1 = ay - dist[1], x2 = ax + dist[2], y2 = ay + dist[3];
+    __syncthreads();
+    if (a_ < na) tile[a_ * pitch + side] = dist;     // l,t,r,b overwrite the first 4 box logits
+    __syncthreads();
+    const int no = 4 + p.nc + p.nm;
+    float* out = p.pred + (size_t)b * no * p.A + p.a0[l] + la0;
     const float st = (float)p.stride[l];
-    out[0 * (size_t)p.A] = ((x1 + x2) / 2.0f) * st;
-    out[1 * (size_t)p.A] = ((y1 + y2) / 2.0f) * st;
-    out[2 * (size_t)p.A] = (x2 - x1) * st;
-    out[3 * (size_t)p.A] = (y2 - y1) * st;
-    const float* cl = p.cls[l] + pix * p.nc;
-    for (int c = 0; c < p.nc; ++c) out[(size_t)(4 + c) * p.A] = 1.0f / (1.0f + expf(-cl[c]));
-    const float* mc = p.mc[l] + pix * p.nm;
-    for (int c = 0; c < p.nm; ++c) out[(size_t)(4 + p.nc + c) * p.A] = mc[c];
+    for (int i = tid; i < no * DEC_TA; i += 256) {
+        const int ch = i >> 6, a = i & 63;
+        if (a >= na) continue;
+        const float* r = tile + a * pitch;
+        float v;
+        if (ch < 4) {
+            const int la = la0 + a;
+            const int gy = la / W, gx = la - gy * W;
+            const float ax = (float)gx + 0.5f, ay = (float)gy + 0.5f;
+            const float x1 = ax - r[0], y1 = ay - r[1], x2 = ax + r[2], y2 = ay + r[3];
+            v = ch == 0 ? ((x1 + x2) / 2.0f) * st : ch == 1 ? ((y1 + y2) / 2.0f) * st : ch == 2 ? (x2 - x1) * st : (y2 - y1) * st;
+        } else if (ch < 4 + p.nc) {
+            v = 1.0f / (1.0f + expf(-r[nbox + ch - 4]));
+        } else {
+            v = r[nbox + ch - 4];
+        }
+        out[(size_t)ch * p.A + a] = v;
+    }
 }
 
 hipError_t launch_decode(const DecodeParams& p, hipStream_t st) {
-    const long total = (long)p.B * p.A;
-    if (total == 0) return hipSuccess;
-    hipLaunchKernelGGL(decode_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p);
+    if ((long)p.B * p.A == 0) return hipSuccess;
+    if (p.reg_max != 16) return hipErrorInvalidValue;
+    int tiles[3];
+    for (int l = 0; l < 3; ++l) tiles[l] = (p.H[l] * p.W[l] + DEC_TA - 1) / DEC_TA;
+    const int tpf = tiles[0] + tiles[1] + tiles[2];
+    const size_t lds = (size_t)DEC_TA * (4 * p.reg_max + p.nc + p.nm + 1) * sizeof(float);
+    if (lds > 64 * 1024) return hipErrorInvalidValue;     // nc up to ~150 classes
+    hipLaunchKernelGGL(decode_kernel, dim3((unsigned)(p.B * tpf)), dim3(256), lds, st, p, tiles[0], tiles[1], tpf);
     return hipGetLastError();
 }
 

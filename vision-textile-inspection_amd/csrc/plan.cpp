@@ -123,6 +123,7 @@ void choose_conv_cfg(int dtype, const ConvRow& r, bool conv0, int max_batch, Con
                 const int PH = conv0 ? TH : (TH - 1) * st + ks, PW = conv0 ? TW : (TW - 1) * st + ks;
                 const size_t lds = conv_lds_bytes(ks, st, conv0 ? 1 : 0, TH, TW, WN, NREP);
                 if (lds > ((fth || ftw) ? 160u : 80u) * 1024) continue;
+                if (!conv_cfg_fits(ks, st, conv0 ? 1 : 0, TH, TW, WN, NREP)) continue;
                 // score: MFMA efficiency, mild preference for compact input patches (halo re-reads),
                 // for bigger per-wave register tiles (LDS traffic per MFMA ~ 1/NREP + 1/5), for long
                 // contiguous tile rows (coalescing) and for >= 2 workgroups per CU of LDS.

@@ -5,6 +5,7 @@
 // Error convention: every entry point returns a vti_status and records a message; nothing
 // throws across the boundary and nothing aborts (measurement.py:207-216 expects predict
 // failures to be survivable).
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -169,6 +170,13 @@ static void fill_conv_params(ConvParams& p, const ConvRow& r, const ConvCfg& g, 
     p.swap_rb = swap_rb ? 1 : 0;
     p.nchunks = g.nchunks; p.ntiles_n = g.ntiles_n;
     p.scalar_store = (g.gemm_n % 4 || out_ld % 4 || out_coff % 4) ? 1 : 0;
+    const bool conv0 = r.c1 == 3;
+    const int ks = deconv ? 1 : r.k, st = deconv ? 1 : r.s;
+    const unsigned PW = conv0 ? (unsigned)g.TW : (unsigned)((g.TW - 1) * st + ks);
+    p.pw_magic = (unsigned)((0x100000000ull + PW - 1) / PW);
+    const unsigned RWB = (unsigned)(2 * g.TW + 1) * 3;
+    p.rw_magic = (unsigned)((0x100000000ull + RWB - 1) / RWB);
+    p.tw_magic = (unsigned)((0x100000000ull + (unsigned)g.TW - 1) / (unsigned)g.TW);
 }
 
 int32_t vti_forward(vti_ctx* c, const uint8_t* input, int32_t B, int32_t swap_rb, float* pred, void* proto, void* stream) {
@@ -369,6 +377,40 @@ int32_t vti_debug_conv2d(int32_t dtype, const void* dev_in, int32_t B, int32_t H
         fill_conv_params(p, r, g, B, dev_in, in_ld, in_coff, dev_out, out_ld, out_coff, dev_res, res_ld, res_coff, d_w, d_b,
                          out_f32 != 0, swap_rb);
         const int ks = kind == 2 ? 1 : k, ss = kind == 2 ? 1 : s;
+#ifdef VTI_STAMPS
+        {   // diagnostic build: one stamped launch, medians of the phase intervals to stderr
+            const int NTB = g.WN * g.NREP;
+            const size_t nwg = (size_t)B * p.tiles_y * p.tiles_x * ((g.ntiles_n + NTB - 1) / NTB);
+            unsigned long long* d_st = nullptr;
+            if (hipMalloc((void**)&d_st, nwg * 16 * 8) == hipSuccess) {
+                (void)hipMemset(d_st, 0, nwg * 16 * 8);
+                (void)launch_conv(dtype, ks, ss, g.NREP, conv0 ? 1 : 0, p, g.lds, st);   // warm caches/icache
+                p.stamps = d_st;
+                (void)launch_conv(dtype, ks, ss, g.NREP, conv0 ? 1 : 0, p, g.lds, st);
+                (void)hipStreamSynchronize(st);
+                std::vector<unsigned long long> h(nwg * 16);
+                (void)hipMemcpy(h.data(), d_st, nwg * 16 * 8, hipMemcpyDeviceToHost);
+                p.stamps = nullptr;
+                (void)hipFree(d_st);
+                const char* names[16] = {"start", "c0:top", "c0:A staged", "c0:B staged", "c0:barrier", "c0:mfma done",
+                                         "c1:top", "c1:A staged", "c1:B staged", "c1:barrier", "c1:mfma done", "epilogue start", "end", "", "", ""};
+                fprintf(stderr, "[stamps] %zu workgroups; median cycles since previous stamp (100 MHz s_memtime ticks x clock)\n", nwg);
+                int prev = 0;
+                for (int i = 1; i <= 12; ++i) {
+                    std::vector<long long> d;
+                    for (size_t w = 0; w < nwg; ++w) if (h[w * 16 + i] && h[w * 16 + prev]) d.push_back((long long)(h[w * 16 + i] - h[w * 16 + prev]));
+                    if (d.empty()) continue;
+                    std::sort(d.begin(), d.end());
+                    fprintf(stderr, "[stamps] %-16s median %8lld  p10 %8lld  p90 %8lld\n", names[i], d[d.size() / 2], d[d.size() / 10], d[d.size() * 9 / 10]);
+                    prev = i;
+                }
+                std::vector<long long> tot;
+                for (size_t w = 0; w < nwg; ++w) tot.push_back((long long)(h[w * 16 + 12] - h[w * 16]));
+                std::sort(tot.begin(), tot.end());
+                fprintf(stderr, "[stamps] whole workgroup   median %8lld\n", tot[tot.size() / 2]);
+            }
+        }
+#endif
         e = launch_conv(dtype, ks, ss, g.NREP, conv0 ? 1 : 0, p, g.lds, st);   // warm-up / the checked run
         if (e == hipSuccess) e = hipEventRecord(e0, st);
         for (int i = 1; i < iters && e == hipSuccess; ++i) e = launch_conv(dtype, ks, ss, g.NREP, conv0 ? 1 : 0, p, g.lds, st);

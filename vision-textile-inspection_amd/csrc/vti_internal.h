@@ -87,12 +87,15 @@ struct ConvParams {
     int out_ld, out_coff, res_ld, res_coff;
     int TH, TW, tiles_y, tiles_x, WN;
     int act, out_f32, deconv_c, swap_rb, nchunks, ntiles_n, has_res, scalar_store;
+    unsigned pw_magic, rw_magic, tw_magic;   // ceil(2^32 / {PW, raw-row-bytes, TW}): division-free indexing
+    unsigned long long* stamps;          // diagnostic build only (VTI_STAMPS): 16 s_memtime slots per workgroup
 };
 
 // dtype: VTI_F16/VTI_F32; mode 0 = NHWC conv, 1 = conv0 (u8 input, im2col K=27->32)
 hipError_t launch_conv(int dtype, int ks, int stride, int nrep, int mode, const ConvParams& p,
                        size_t lds_bytes, hipStream_t st);
 size_t conv_lds_bytes(int ks, int stride, int mode, int TH, int TW, int WN, int NREP);
+bool conv_cfg_fits(int ks, int stride, int mode, int TH, int TW, int WN, int NREP);
 
 struct PoolParams { const void* in; void* out; int B, H, W, C, ld, in_coff, out_coff; };
 hipError_t launch_sppf_pool(int dtype, const PoolParams& p, hipStream_t st);
