@@ -1,0 +1,56 @@
+#!/bin/bash
+# Runs on the GPU box (via gpurun): rocprofv3 evidence for bench.py, copied to profiles/ by the caller.
+#   1. --kernel-trace --stats of the bench command           -> gpurun_out/profiles/<tag>_kernel_stats.csv + summary
+#   2. --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes)-> per-forward HBM traffic of the conv family
+tag=${1:-r01}
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+out=gpurun_out/profiles; mkdir -p $out; rm -rf gpurun_out/_p1 gpurun_out/_p2 gpurun_out/_p3
+args="bench.py --steps 10 --warmup 3 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/_p1 -- python3 $args > $out/${tag}_bench_under_rocprof.json 2> gpurun_out/_p1.err || exit 1
+cp $(find gpurun_out/_p1 -name '*kernel_stats.csv' | head -1) $out/${tag}_bench_kernel_stats.csv
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/_p2 -- python3 $args > /dev/null 2> gpurun_out/_p2.err || exit 1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/_p3 -- python3 $args > /dev/null 2> gpurun_out/_p3.err || exit 1
+python3 - "$tag" <<'PY'
+import csv, glob, collections, json, sys
+tag = sys.argv[1]
+out = "gpurun_out/profiles"
+def fam(n):
+    if "conv_kernel" in n or "stem_kernel" in n: return "conv family (conv_kernel + stem_kernel)"
+    for k in ("decode_kernel", "masks_kernel", "nms_kernel", "nms_scan_kernel", "mask_plan_kernel", "mask_offsets_kernel",
+              "sppf_pool", "upsample2x", "scale_boxes", "letterbox"):
+        if k in n: return k
+    return None
+# ---- kernel trace: per-family totals over the run
+f = glob.glob("gpurun_out/_p1/**/*kernel_trace.csv", recursive=True)[0]
+agg = collections.defaultdict(list)
+for r in csv.DictReader(open(f)):
+    k = fam(r["Kernel_Name"])
+    if k: agg[k].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+nfwd = len(agg["decode_kernel"])            # one decode per forward
+lines = [f"rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline   ({nfwd} forwards incl. calibration/warm-up)",
+         f"{'kernel family':44s} {'calls':>7s} {'avg us':>10s} {'us/forward':>12s}"]
+for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
+    lines.append(f"{k:44s} {len(v):7d} {sum(v)/len(v)/1e3:10.1f} {sum(v)/nfwd/1e3:12.1f}")
+open(f"{out}/{tag}_bench_kernel_summary.txt", "w").write("\n".join(lines) + "\n")
+print("\n".join(lines))
+# ---- PMC: HBM bytes of the conv family per forward (bs=64).  FETCH_SIZE/WRITE_SIZE are in KiB; gfx950 reports
+# half the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM), so fetch is doubled.
+def pmc_sum(d, name):
+    f = glob.glob(f"{d}/**/*counter_collection.csv", recursive=True)[0]
+    tot = collections.defaultdict(float); cnt = collections.Counter()
+    for r in csv.DictReader(open(f)):
+        k = fam(r["Kernel_Name"])
+        if k and r["Counter_Name"] == name:
+            tot[k] += float(r["Counter_Value"]); cnt[k] += 1
+    return tot, cnt
+ft, fc = pmc_sum("gpurun_out/_p2", "FETCH_SIZE")
+wt, wc = pmc_sum("gpurun_out/_p3", "WRITE_SIZE")
+nf = fc["decode_kernel"]; nw = wc["decode_kernel"]
+res = {"note": "HBM traffic per forward (bs=64) from rocprofv3 PMC, separate passes; FETCH_SIZE x2 correction for gfx950 applied",
+       "families": {}}
+for k in ft:
+    fetch = ft[k] / nf * 1024 * 2; write = wt.get(k, 0.0) / max(nw, 1) * 1024
+    res["families"][k] = {"fetch_bytes": fetch, "write_bytes": write, "total_bytes": fetch + write}
+json.dump(res, open(f"{out}/{tag}_hbm_traffic.json", "w"), indent=1)
+print(json.dumps(res["families"].get("conv family (conv_kernel + stem_kernel)"), indent=1))
+PY

@@ -72,7 +72,10 @@ constexpr int MREP = 5;
 
 __host__ __device__ inline int patch_dim(int t, int ks, int s, int mode) { return mode == 1 ? t : (t - 1) * s + ks; }
 
+size_t stem_lds_bytes(int TH, int TW);
+
 size_t conv_lds_bytes(int ks, int stride, int mode, int TH, int TW, int WN, int NREP) {
+    if (mode == 1) return stem_lds_bytes(TH, TW);
     const int npix = patch_dim(TH, ks, stride, mode) * patch_dim(TW, ks, stride, mode);
     const size_t plane = (size_t)((npix + 15) & ~15) * 16;
     const int taps = mode == 1 ? 1 : ks * ks;
@@ -80,6 +83,122 @@ size_t conv_lds_bytes(int ks, int stride, int mode, int TH, int TW, int WN, int 
     if (mode == 1) raw = (((size_t)(2 * TH + 1) * (2 * TW + 1) * 3) + 15) & ~(size_t)15;   // u8 input patch
     return 4 * plane + (size_t)WN * NREP * taps * 1024 + raw;
 }
+
+// ---- shared epilogue: bias, SiLU, residual, store 4 consecutive channels per lane.
+template <typename T, int NREP>
+__device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc)[MREP][NREP], const bool (&pvalid)[MREP],
+                                              const int (&opy)[MREP], const int (&opx)[MREP], int b, int nt0, int wn,
+                                              int lane) {
+    // Bias (and the residual of a whole pixel row) are loaded up front: a load inside the store loop
+    // would make every block wait on vmcnt(0), i.e. on all earlier STORES as well.
+    constexpr bool FAST = sizeof(T) == 2;
+    f32x4 bias_r[NREP];
+    int cout_r[NREP];
+#pragma unroll
+    for (int n = 0; n < NREP; ++n) {
+        cout_r[n] = (nt0 + wn * NREP + n) * 16 + (lane >> 4) * 4;
+        const int cb = cout_r[n] < p.ntiles_n * 16 ? cout_r[n] : 0;     // bias is padded to 16 floats per n-tile
+        bias_r[n] = *(const f32x4*)(p.bias + cb);
+    }
+    if (!p.scalar_store && !p.out_f32 && !p.deconv_c) {
+        // common case: T output, vector stores, plain NHWC addressing -- no per-element branches
+        const bool has_res = __builtin_amdgcn_readfirstlane(p.has_res) != 0;
+#pragma unroll
+        for (int m = 0; m < MREP; ++m) {
+            if (!pvalid[m]) continue;
+            const size_t opix = ((size_t)(b * p.Hout + opy[m])) * p.Wout + opx[m];
+            T* op = (T*)p.out + opix * p.out_ld + p.out_coff;
+            f32x4 res_r[NREP];
+            if (has_res) {
+                const T* rp = (const T*)p.res + opix * p.res_ld + p.res_coff;
+#pragma unroll
+                for (int n = 0; n < NREP; ++n) {
+                    res_r[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if (cout_r[n] < p.Cout) {
+                        if constexpr (sizeof(T) == 2) {
+                            const half4 r = *(const half4*)(rp + cout_r[n]);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) res_r[n][j] = (float)r[j];
+                        } else {
+                            res_r[n] = *(const f32x4*)(rp + cout_r[n]);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int n = 0; n < NREP; ++n) {
+                if (cout_r[n] >= p.Cout) continue;
+                f32x4 v = acc[m][n] + bias_r[n];
+                if (p.act) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = silu<FAST>(v[j]);
+                }
+                if (has_res) v += res_r[n];
+                if constexpr (sizeof(T) == 2) {
+                    half4 hv;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) hv[j] = (half_t)v[j];
+                    *(half4*)(op + cout_r[n]) = hv;
+                } else {
+                    *(f32x4*)(op + cout_r[n]) = v;
+                }
+            }
+        }
+        return;
+    }
+    // general case: fp32 head outputs, ragged channel counts (scalar stores), ConvTranspose scatter
+#pragma unroll
+    for (int m = 0; m < MREP; ++m) {
+        if (!pvalid[m]) continue;
+#pragma unroll
+        for (int n = 0; n < NREP; ++n) {
+            const int cout0 = cout_r[n];
+            if (cout0 >= p.Cout) continue;
+            f32x4 v = acc[m][n] + bias_r[n];
+            if (p.act) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = silu<FAST>(v[j]);
+            }
+            size_t opix;
+            int co = cout0;
+            if (p.deconv_c) {
+                const int q = cout0 / p.deconv_c;
+                co = cout0 - q * p.deconv_c;
+                opix = ((size_t)(b * 2 * p.Hout + 2 * opy[m] + (q >> 1))) * (2 * p.Wout) + 2 * opx[m] + (q & 1);
+            } else {
+                opix = ((size_t)(b * p.Hout + opy[m])) * p.Wout + opx[m];
+            }
+            if (p.has_res) {
+                const T* rp = (const T*)p.res + opix * p.res_ld + p.res_coff + co;
+                if constexpr (sizeof(T) == 2) {
+                    const half4 r = *(const half4*)rp;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] += (float)r[j];
+                } else {
+                    v += *(const f32x4*)rp;
+                }
+            }
+            const size_t o = opix * p.out_ld + p.out_coff + co;
+            if (p.scalar_store) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (cout0 + j < p.Cout) {
+                        if (p.out_f32) ((float*)p.out)[o + j] = v[j];
+                        else ((T*)p.out)[o + j] = (T)v[j];
+                    }
+                }
+            } else if (p.out_f32 || sizeof(T) == 4) {
+                *(f32x4*)((float*)p.out + o) = v;
+            } else {
+                half4 hv;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) hv[j] = (half_t)v[j];
+                *(half4*)((half_t*)p.out + o) = hv;
+            }
+        }
+    }
+}
+
 
 // Register-staged operand prefetch: a thread owns up to AR input-patch pieces and BR weight pieces
 // (16 B each) of a chunk.  issue() only starts the global loads; commit() writes them to LDS.  The
@@ -145,11 +264,14 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvParams p) {
     if constexpr (MODE == 0) {
 #pragma unroll
         for (int u = 0; u < AR; ++u) {
+            // item -> (pixel, 16-B channel piece q): 8 consecutive lanes take 8 consecutive pixels of ONE
+            // plane (a conflict-free 128-B ds_write run); a wave instruction still covers 16 pixels x 64 B
+            // of global memory, i.e. the same cache lines as a pixel-major order would.
             const int i = tid + u * 256;
-            const int pix = i >> 2, q = i & 3;
+            const int pix = (i >> 5) * 8 + (i & 7), q = (i >> 3) & 3;
             const int py = (int)__umulhi((unsigned)pix, p.pw_magic), px = pix - py * PW;
             const int y = iy0 + py, x = ix0 + px;
-            const bool ok = i < nitemA && (unsigned)y < (unsigned)p.Hin && (unsigned)x < (unsigned)p.Win;
+            const bool ok = pix < npix && (unsigned)y < (unsigned)p.Hin && (unsigned)x < (unsigned)p.Win;
             aoff[u] = ok ? (long)(((size_t)(b * p.Hin + y) * p.Win + x) * p.in_ld + p.in_coff + q * VEC) : -1;
         }
     }
@@ -161,7 +283,7 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvParams p) {
             for (int u = 0; u < AR; ++u) {
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) ra[u][j] = 0;
-                if (aoff[u] >= 0 && c * KC + (tid & 3) * VEC < p.Cin) ra[u] = *(const vec*)(inb + aoff[u] + c * KC);
+                if (aoff[u] >= 0 && c * KC + ((tid >> 3) & 3) * VEC < p.Cin) ra[u] = *(const vec*)(inb + aoff[u] + c * KC);
             }
         }
         const vec* wsrc = (const vec*)p.wpk + ((size_t)c * p.ntiles_n + nt0) * (TAPS * 64);
@@ -178,7 +300,8 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvParams p) {
 #pragma unroll
             for (int u = 0; u < AR; ++u) {
                 const int i = tid + u * 256;
-                if (i < nitemA) *(vec*)(smA + (i & 3) * plane_bytes + (i >> 2) * 16) = ra[u];
+                const int pix = (i >> 5) * 8 + (i & 7), q = (i >> 3) & 3;
+                if (pix < npix) *(vec*)(smA + q * plane_bytes + pix * 16) = ra[u];
             }
         } else {
             // conv0: im2col from the u8 patch staged in LDS: k = (kh*3+kw)*3 + channel, K = 27 -> 32
@@ -256,125 +379,112 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvParams p) {
     }
 
     VTI_STAMP(11);
-    // ---- epilogue: bias, SiLU, residual, store 4 consecutive channels per lane.
-    // Bias (and the residual of a whole pixel row) are loaded up front: a load inside the store loop
-    // would make every block wait on vmcnt(0), i.e. on all earlier STORES as well.
-    constexpr bool FAST = sizeof(T) == 2;
-    f32x4 bias_r[NREP];
-    int cout_r[NREP];
-#pragma unroll
-    for (int n = 0; n < NREP; ++n) {
-        cout_r[n] = (nt0 + wn * NREP + n) * 16 + (lane >> 4) * 4;
-        const int cb = cout_r[n] < p.ntiles_n * 16 ? cout_r[n] : 0;     // bias is padded to 16 floats per n-tile
-        bias_r[n] = *(const f32x4*)(p.bias + cb);
-    }
-    if (!p.scalar_store && !p.out_f32 && !p.deconv_c) {
-        // common case: T output, vector stores, plain NHWC addressing -- no per-element branches
-        const bool has_res = __builtin_amdgcn_readfirstlane(p.has_res) != 0;
-#pragma unroll
-        for (int m = 0; m < MREP; ++m) {
-            if (!pvalid[m]) continue;
-            const size_t opix = ((size_t)(b * p.Hout + opy[m])) * p.Wout + opx[m];
-            T* op = (T*)p.out + opix * p.out_ld + p.out_coff;
-            f32x4 res_r[NREP];
-            if (has_res) {
-                const T* rp = (const T*)p.res + opix * p.res_ld + p.res_coff;
-#pragma unroll
-                for (int n = 0; n < NREP; ++n) {
-                    res_r[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    if (cout_r[n] < p.Cout) {
-                        if constexpr (sizeof(T) == 2) {
-                            const half4 r = *(const half4*)(rp + cout_r[n]);
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) res_r[n][j] = (float)r[j];
-                        } else {
-                            res_r[n] = *(const f32x4*)(rp + cout_r[n]);
-                        }
-                    }
-                }
-            }
-#pragma unroll
-            for (int n = 0; n < NREP; ++n) {
-                if (cout_r[n] >= p.Cout) continue;
-                f32x4 v = acc[m][n] + bias_r[n];
-                if (p.act) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = silu<FAST>(v[j]);
-                }
-                if (has_res) v += res_r[n];
-                if constexpr (sizeof(T) == 2) {
-                    half4 hv;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) hv[j] = (half_t)v[j];
-                    *(half4*)(op + cout_r[n]) = hv;
-                } else {
-                    *(f32x4*)(op + cout_r[n]) = v;
-                }
-            }
-        }
-        VTI_STAMP(12);
-        return;
-    }
-    // general case: fp32 head outputs, ragged channel counts (scalar stores), ConvTranspose scatter
-#pragma unroll
-    for (int m = 0; m < MREP; ++m) {
-        if (!pvalid[m]) continue;
-#pragma unroll
-        for (int n = 0; n < NREP; ++n) {
-            const int cout0 = cout_r[n];
-            if (cout0 >= p.Cout) continue;
-            f32x4 v = acc[m][n] + bias_r[n];
-            if (p.act) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = silu<FAST>(v[j]);
-            }
-            size_t opix;
-            int co = cout0;
-            if (p.deconv_c) {
-                const int q = cout0 / p.deconv_c;
-                co = cout0 - q * p.deconv_c;
-                opix = ((size_t)(b * 2 * p.Hout + 2 * opy[m] + (q >> 1))) * (2 * p.Wout) + 2 * opx[m] + (q & 1);
-            } else {
-                opix = ((size_t)(b * p.Hout + opy[m])) * p.Wout + opx[m];
-            }
-            if (p.has_res) {
-                const T* rp = (const T*)p.res + opix * p.res_ld + p.res_coff + co;
-                if constexpr (sizeof(T) == 2) {
-                    const half4 r = *(const half4*)rp;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] += (float)r[j];
-                } else {
-                    v += *(const f32x4*)rp;
-                }
-            }
-            const size_t o = opix * p.out_ld + p.out_coff + co;
-            if (p.scalar_store) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (cout0 + j < p.Cout) {
-                        if (p.out_f32) ((float*)p.out)[o + j] = v[j];
-                        else ((T*)p.out)[o + j] = (T)v[j];
-                    }
-                }
-            } else if (p.out_f32 || sizeof(T) == 4) {
-                *(f32x4*)((float*)p.out + o) = v;
-            } else {
-                half4 hv;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) hv[j] = (half_t)v[j];
-                *(half4*)((half_t*)p.out + o) = hv;
-            }
-        }
-    }
+    conv_epilogue<T, NREP>(p, acc, pvalid, opy, opx, b, nt0, wn, lane);
     VTI_STAMP(12);
 }
 
+// ---- stem conv (model.0): u8 HWC3 frame -> /255 -> 3x3 stride-2 conv, K = 27 padded to 32.
+// The (2TH+1) x (2TW+1) x 3-byte input patch is copied to LDS with aligned dword loads; an exact
+// 256-entry table gives T(v/255.0f) (what torch computes for `im.float()/255`, then .half()); every
+// lane gathers its MFMA pixel-operand fragment (k = (kh*3+kw)*3 + channel) straight from the LDS
+// bytes, so no im2col image is materialised.  Weights are read as fragments from L2 (1 KiB/wave).
+template <typename T, int NREP>
+__global__ __launch_bounds__(256) void stem_kernel(const ConvParams p) {
+    using vec = typename Tr<T>::vec;
+    constexpr int VEC = Tr<T>::VEC, KC = Tr<T>::KC;
+    constexpr int NCH = 32 / KC;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* lut = (T*)smem;                                  // 256 entries, 1 KiB reserved
+    unsigned* raw32 = (unsigned*)(smem + 1024);
+    const unsigned char* raw = (const unsigned char*)raw32;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int t = blockIdx.x;
+    const int tx = t % p.tiles_x; t /= p.tiles_x;
+    const int ty = t % p.tiles_y;
+    const int b = t / p.tiles_y;
+    const int oy0 = ty * p.TH, ox0 = tx * p.TW;
+    const int RH = 2 * p.TH + 1, RWB = (2 * p.TW + 1) * 3;
+    const int RWD = (RWB + 6) >> 2;                     // dwords per patch row incl. alignment slack
+    const int pitch = RWD * 4;
+    const int x0b = (ox0 * 2 - 1) * 3, a0 = x0b & ~3, shift = x0b - a0;
+    const int y0 = oy0 * 2 - 1;
+    const uint8_t* inb = (const uint8_t*)p.in + (size_t)b * p.Hin * p.Win * 3;
+    const int rowbytes = p.Win * 3;                     // multiple of 4 in the product (W % 32 == 0)
+    for (int i = tid; i < RH * RWD; i += 256) {
+        const int ry = (int)__umulhi((unsigned)i, p.rw_magic), rd = i - ry * RWD;
+        const int y = y0 + ry, gx = a0 + 4 * rd;
+        unsigned v = 0;
+        if ((unsigned)y < (unsigned)p.Hin) {
+            if ((rowbytes & 3) == 0) {      // aligned rows: a dword is wholly inside or outside the row
+                if (gx >= 0 && gx < rowbytes) v = *(const unsigned*)(inb + (size_t)y * rowbytes + gx);
+            } else {                        // ragged width (tests only): assemble byte by byte
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (gx + k >= 0 && gx + k < rowbytes) v |= (unsigned)inb[(size_t)y * rowbytes + gx + k] << (8 * k);
+            }
+        }
+        raw32[i] = v;
+    }
+    lut[tid] = (T)((float)tid / 255.0f);
+    __syncthreads();
+
+    const int tile_px = p.TH * p.TW;
+    const int nt0 = blockIdx.y * NREP;
+    int opy[MREP], opx[MREP], rbase[MREP];
+    bool pvalid[MREP];
+#pragma unroll
+    for (int m = 0; m < MREP; ++m) {
+        const int pp = (wave * MREP + m) * 16 + (lane & 15);
+        const bool v = pp < tile_px;
+        const int pc = v ? pp : 0;
+        const int py = (int)__umulhi((unsigned)pc, p.tw_magic), px = pc - py * p.TW;
+        opy[m] = oy0 + py; opx[m] = ox0 + px;
+        pvalid[m] = v && opy[m] < p.Hout && opx[m] < p.Wout;
+        rbase[m] = (py * 2) * pitch + (px * 2) * 3 + shift;
+    }
+    f32x4 acc[MREP][NREP];
+#pragma unroll
+    for (int m = 0; m < MREP; ++m)
+#pragma unroll
+        for (int n = 0; n < NREP; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        int off[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const int k = c * KC + (lane >> 4) * VEC + j;
+            const int tap = k / 3, chn = k - tap * 3;
+            const int kh = tap / 3, kw = tap - kh * 3;
+            off[j] = k < 27 ? kh * pitch + kw * 3 + (p.swap_rb ? 2 - chn : chn) : -1;
+        }
+        vec w[NREP];
+#pragma unroll
+        for (int n = 0; n < NREP; ++n) {
+            const int nt = nt0 + n < p.ntiles_n ? nt0 + n : 0;
+            w[n] = ((const vec*)p.wpk)[((size_t)c * p.ntiles_n + nt) * 64 + lane];
+        }
+#pragma unroll
+        for (int m = 0; m < MREP; ++m) {
+            vec x;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) x[j] = off[j] >= 0 ? lut[raw[rbase[m] + off[j]]] : (T)0;
+#pragma unroll
+            for (int n = 0; n < NREP; ++n) acc[m][n] = mma(w[n], x, acc[m][n]);
+        }
+    }
+    conv_epilogue<T, NREP>(p, acc, pvalid, opy, opx, b, nt0, 0, lane);
+}
+
+size_t stem_lds_bytes(int TH, int TW) { return 1024 + (size_t)(2 * TH + 1) * ((((2 * TW + 1) * 3 + 6) >> 2) * 4); }
+
 // Host-side check that a geometry fits the kernel's fixed register staging arrays.
 bool conv_cfg_fits(int ks, int stride, int mode, int TH, int TW, int WN, int NREP) {
+    if (mode == 1) return WN == 1 && (2 * TH + 1) * (((2 * TW + 1) * 3 + 6) >> 2) < 65536;
     const int taps = mode == 1 ? 1 : ks * ks;
     const int AR = mode == 1 ? 1 : (stride == 2 ? 12 : 8), BR = taps == 1 ? 5 : 12;
     const int npix = patch_dim(TH, ks, stride, mode) * patch_dim(TW, ks, stride, mode);
-    if (mode == 0 && npix * 4 > 256 * AR) return false;
+    if (mode == 0 && ((npix + 7) / 8) * 32 > 256 * AR) return false;
     return WN * NREP * taps * 64 <= 256 * BR;
 }
 
@@ -402,7 +512,14 @@ static hipError_t launch_nrep(int nrep, const ConvParams& p, dim3 grid, size_t l
 template <typename T>
 static hipError_t launch_t(int ks, int stride, int nrep, int mode, const ConvParams& p, dim3 grid, size_t lds,
                            hipStream_t st) {
-    if (mode == 1) return launch_nrep<T, 3, 2, 1>(nrep, p, grid, lds, st);
+    if (mode == 1) {
+        switch (nrep) {
+#define VTI_STEM(N) case N: hipLaunchKernelGGL((stem_kernel<T, N>), grid, dim3(256), lds, st, p); return hipGetLastError();
+            VTI_STEM(1) VTI_STEM(2) VTI_STEM(3) VTI_STEM(4) VTI_STEM(5)
+#undef VTI_STEM
+            default: return hipErrorInvalidValue;
+        }
+    }
     if (ks == 1 && stride == 1) return launch_nrep<T, 1, 1, 0>(nrep, p, grid, lds, st);
     if (ks == 3 && stride == 1) return launch_nrep<T, 3, 1, 0>(nrep, p, grid, lds, st);
     if (ks == 3 && stride == 2) return launch_nrep<T, 3, 2, 0>(nrep, p, grid, lds, st);

@@ -127,7 +127,8 @@ void choose_conv_cfg(int dtype, const ConvRow& r, bool conv0, int max_batch, Con
                 // score: MFMA efficiency, mild preference for compact input patches (halo re-reads),
                 // for bigger per-wave register tiles (LDS traffic per MFMA ~ 1/NREP + 1/5), for long
                 // contiguous tile rows (coalescing) and for >= 2 workgroups per CU of LDS.
-                const double halo = (double)(TH * TW * st * st) / (PH * PW);
+                const double halo = conv0 ? (double)(4 * TH * TW) / ((2 * TH + 1) * (2 * TW + 1))
+                                          : (double)(TH * TW * st * st) / (PH * PW);
                 const double lds_traffic = 1.0 / NREP + 1.0 / 5;
                 const double rowb = std::min(1.0, (double)TW * 64.0 / 1024.0);
                 double score = m_eff * n_eff * (0.6 + 0.4 * halo) * (0.8 + 0.2 * rowb) / (0.35 + lds_traffic);

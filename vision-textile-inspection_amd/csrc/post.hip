@@ -94,7 +94,8 @@ hipError_t launch_letterbox(const uint8_t* frames, int B, int H0, int W0, uint8_
 // =====================================================================================
 // U6 non_max_suppression -- one 1024-thread workgroup per frame
 // =====================================================================================
-constexpr int NMS_THREADS = 1024;
+constexpr int NMS_THREADS = 512;
+constexpr int NMS_LDS_BOX = 2048;         // sorted boxes/areas/keep list live in LDS up to this many candidates
 constexpr int NMS_LDS_KEYS = 8192;        // candidates sorted in LDS up to this many, else in global scratch
 constexpr float NMS_MAX_WH = 7680.0f;     // Ultralytics class offset
 
@@ -113,49 +114,55 @@ static NmsWsLayout nms_layout(int A) {
     l.per_frame = off;
     return l;
 }
-size_t nms_workspace_bytes(int B, int A) { return nms_layout(A).per_frame * (size_t)B; }
+size_t nms_workspace_bytes(int B, int A) { return nms_layout(A).per_frame * (size_t)B + align256((size_t)B * 4); }
 
+// Stage 1 (whole chip): best class score per anchor (first maximal index); anchors above `conf` are
+// appended to the frame's key list.  Arrival order is arbitrary -- the sort below restores the order.
+__global__ __launch_bounds__(256) void nms_scan_kernel(const float* __restrict__ pred, int A, int nc, int nm, float conf,
+                                                       char* ws, NmsWsLayout L, int* __restrict__ ncand) {
+    const int b = blockIdx.y;
+    const int a = blockIdx.x * 256 + threadIdx.x;
+    if (a >= A) return;
+    const float* P = pred + (size_t)b * (4 + nc + nm) * A;
+    float best = P[(size_t)4 * A + a];
+    int j = 0;
+    for (int c = 1; c < nc; ++c) {
+        const float v = P[(size_t)(4 + c) * A + a];
+        if (v > best) { best = v; j = c; }
+    }
+    if (best > conf) {
+        char* wsb = ws + (size_t)b * L.per_frame;
+        const int idx = atomicAdd(&ncand[b], 1);
+        // ascending key order == score descending, then anchor ascending (stable sort of the
+        // anchor-ordered candidate list, as torchvision's stable descending sort).
+        ((unsigned long long*)(wsb + L.keys))[idx] = ((unsigned long long)(~__float_as_uint(best)) << 32) | (unsigned)a;
+        ((int*)(wsb + L.cls))[a] = j;
+    }
+}
+
+// Stage 2: one workgroup per frame -- sort, greedy suppression, output rows.
 __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const float* __restrict__ pred, int A, int nc, int nm,
                                                           float conf, double iou, int max_det, int agnostic,
                                                           float* __restrict__ dets, int* __restrict__ counts,
-                                                          char* ws, NmsWsLayout L) {
+                                                          char* ws, NmsWsLayout L, const int* __restrict__ ncand) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     unsigned long long* lds_keys = (unsigned long long*)smem;             // NMS_LDS_KEYS entries
-    unsigned char* suppressed = (unsigned char*)(smem + NMS_LDS_KEYS * 8); // A bytes
-    __shared__ int s_count;
+    f32x4* lds_boxes = (f32x4*)(smem + NMS_LDS_KEYS * 8);                 // NMS_LDS_BOX entries
+    float* lds_area = (float*)(lds_boxes + NMS_LDS_BOX);
+    int* lds_keep = (int*)(lds_area + NMS_LDS_BOX);
+    unsigned char* suppressed = (unsigned char*)(lds_keep + NMS_LDS_BOX);  // A bytes
 
     const int b = blockIdx.x, tid = threadIdx.x;
     const int no = 4 + nc + nm;
     const float* P = pred + (size_t)b * no * A;
     char* wsb = ws + (size_t)b * L.per_frame;
     unsigned long long* g_keys = (unsigned long long*)(wsb + L.keys);
-    f32x4* boxes = (f32x4*)(wsb + L.boxes);
-    float* area = (float*)(wsb + L.area);
     int* cls_of = (int*)(wsb + L.cls);
-    int* keep = (int*)(wsb + L.keep);
-
-    if (tid == 0) s_count = 0;
-    __syncthreads();
-
-    // 1. candidates: best class score per anchor (first maximal index), kept when > conf.
-    //    Candidates are first parked in the global key array in arrival order.
-    for (int a = tid; a < A; a += NMS_THREADS) {
-        float best = P[(size_t)4 * A + a];
-        int j = 0;
-        for (int c = 1; c < nc; ++c) {
-            const float v = P[(size_t)(4 + c) * A + a];
-            if (v > best) { best = v; j = c; }
-        }
-        if (best > conf) {
-            const int idx = atomicAdd(&s_count, 1);
-            // ascending key order == score descending, then anchor ascending (stable sort of the
-            // anchor-ordered candidate list, as torchvision's stable descending sort).
-            g_keys[idx] = ((unsigned long long)(~__float_as_uint(best)) << 32) | (unsigned)a;
-            cls_of[a] = j;
-        }
-    }
-    __syncthreads();
-    const int n = s_count;
+    const int n = ncand[b];
+    // flat pointers: LDS for the common case, global scratch for pathological candidate counts
+    f32x4* boxes = n <= NMS_LDS_BOX ? lds_boxes : (f32x4*)(wsb + L.boxes);
+    float* area = n <= NMS_LDS_BOX ? lds_area : (float*)(wsb + L.area);
+    int* keep = n <= NMS_LDS_BOX ? lds_keep : (int*)(wsb + L.keep);
     if (n == 0) {
         if (tid == 0) counts[b] = 0;
         for (int i = tid; i < max_det * (6 + nm); i += NMS_THREADS) dets[(size_t)b * max_det * (6 + nm) + i] = 0.f;
@@ -247,156 +254,199 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const float* __restric
 hipError_t launch_nms(const float* pred, int B, int A, int nc, int nm, float conf, double iou, int max_det,
                       int agnostic, float* dets, int* counts, void* ws, hipStream_t st) {
     if (B == 0) return hipSuccess;
-    const size_t lds = (size_t)NMS_LDS_KEYS * 8 + (((size_t)A + 15) & ~(size_t)15);
-    if (lds > 150 * 1024) return hipErrorInvalidValue;   // > ~88k anchors: unsupported
+    const size_t lds = (size_t)NMS_LDS_KEYS * 8 + (size_t)NMS_LDS_BOX * 24 + (((size_t)A + 15) & ~(size_t)15);
+    if (lds > 150 * 1024) return hipErrorInvalidValue;   // > ~39k anchors: unsupported
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
+    const NmsWsLayout L = nms_layout(A);
+    int* ncand = (int*)((char*)ws + L.per_frame * (size_t)B);
+    hipError_t e = hipMemsetAsync(ncand, 0, sizeof(int) * (size_t)B, st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(nms_scan_kernel, dim3((A + 255) / 256, B), dim3(256), 0, st, pred, A, nc, nm, conf, (char*)ws, L, ncand);
     hipLaunchKernelGGL(nms_kernel, dim3(B), dim3(NMS_THREADS), lds, st, pred, A, nc, nm, conf, iou, max_det, agnostic,
-                       dets, counts, (char*)ws, nms_layout(A));
+                       dets, counts, (char*)ws, L, ncand);
     return hipGetLastError();
 }
 
 // =====================================================================================
 // U7 process_mask
 // =====================================================================================
-__global__ void mask_offsets_kernel(const int* __restrict__ counts, int B, int max_det, int* __restrict__ offsets) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        int s = 0;
-        for (int b = 0; b < B; ++b) {
-            offsets[b] = s;
-            int c = counts[b];
-            c = c < 0 ? 0 : (c > max_det ? max_det : c);
-            s += c;
-        }
-        offsets[B] = s;
-    }
-}
-
 constexpr int MT = 64;          // output tile edge
 constexpr int ML = MT / 4 + 3;  // low-res rows/cols needed by one tile at the fixed 1/4 scale (+ slack)
+
+// Plan: exclusive prefix sums of the counts, then one work item per (instance slot, 64x64 output tile)
+// whose low-res footprint can intersect the instance's crop box.  Everything else stays zero (memset).
+// item = slot * tiles + tile.  One workgroup; B and the detection counts are small.
+__global__ __launch_bounds__(256) void mask_offsets_kernel(const int* __restrict__ counts, int B, int max_det,
+                                                           int* __restrict__ offsets, int* __restrict__ nitems) {
+    extern __shared__ int s_off[];      // B + 1 prefix sums
+    for (int b = threadIdx.x; b < B; b += 256) {
+        int c = counts[b];
+        s_off[b + 1] = c < 0 ? 0 : (c > max_det ? max_det : c);
+    }
+    if (threadIdx.x == 0) { s_off[0] = 0; *nitems = 0; }
+    __syncthreads();
+    if (threadIdx.x == 0)
+        for (int b = 0; b < B; ++b) s_off[b + 1] += s_off[b];
+    __syncthreads();
+    for (int b = threadIdx.x; b <= B; b += 256) offsets[b] = s_off[b];
+}
+
+__global__ __launch_bounds__(256) void mask_plan_kernel(const float* __restrict__ dets, const int* __restrict__ offsets, int B,
+                                                        int max_det, int row, int H, int W, int capacity,
+                                                        int2* __restrict__ items, int* __restrict__ nitems) {
+    const int slot = blockIdx.x * 256 + threadIdx.x;
+    const int total = min(offsets[B], capacity);
+    if (slot >= total) return;
+    const int tiles_x = (W + MT - 1) / MT, tiles_y = (H + MT - 1) / MT;
+    int lo = 0, hi = B;                         // largest b with offsets[b] <= slot
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (offsets[mid] <= slot) lo = mid; else hi = mid; }
+    const int inst = slot - offsets[lo];
+    const float* d = dets + ((size_t)lo * max_det + inst) * row;
+    // a tile can be non-zero only if one of its bilinear taps lies inside the box (in 1/4-res
+    // pixels); expand the box by 2 low-res pixels (= 8 output px) to be safe on every side
+    const float x1 = d[0] - 8.f, y1 = d[1] - 8.f, x2 = d[2] + 8.f, y2 = d[3] + 8.f;
+    int tx0 = (int)floorf(x1 / MT), tx1 = (int)floorf(x2 / MT), ty0 = (int)floorf(y1 / MT), ty1 = (int)floorf(y2 / MT);
+    tx0 = max(tx0, 0); ty0 = max(ty0, 0); tx1 = min(tx1, tiles_x - 1); ty1 = min(ty1, tiles_y - 1);
+    const int cnt = (tx1 >= tx0 && ty1 >= ty0) ? (tx1 - tx0 + 1) * (ty1 - ty0 + 1) : 0;
+    if (cnt == 0) return;
+    int base = atomicAdd(nitems, cnt);
+    for (int ty = ty0; ty <= ty1; ++ty)
+        for (int tx = tx0; tx <= tx1; ++tx) items[base++] = make_int2((slot * tiles_y + ty) * tiles_x + tx, (lo << 16) | inst);
+}
 
 template <typename T>
 __global__ __launch_bounds__(256) void masks_kernel(const float* __restrict__ dets, const int* __restrict__ offsets,
                                                     const T* __restrict__ proto, int B, int max_det, int nm, int Hp,
                                                     int Wp, int H, int W, int mode, int packing,
-                                                    uint8_t* __restrict__ masks, int capacity) {
+                                                    uint8_t* __restrict__ masks, const int2* __restrict__ items,
+                                                    const int* __restrict__ nitems) {
     __shared__ float coef[64];
     __shared__ float low[ML][ML + 1];
-    __shared__ int s_b, s_i;
-    const int slot = blockIdx.y, tid = threadIdx.x;
-    if (slot >= capacity) return;
-    if (tid == 0) {
-        // slot -> (frame, instance) by binary search in the exclusive prefix sums
-        int lo = 0, hi = B;     // find largest b with offsets[b] <= slot
-        if (slot >= offsets[B]) { s_b = -1; s_i = 0; }
-        else {
-            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (offsets[mid] <= slot) lo = mid; else hi = mid; }
-            s_b = lo; s_i = slot - offsets[lo];
-        }
-    }
-    __syncthreads();
-    const int b = s_b, inst = s_i;
-    if (b < 0) return;
-    const int tiles_x = (W + MT - 1) / MT;
-    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
-    const int y0 = ty * MT, x0 = tx * MT;
-    const int row = 6 + nm;
-    const float* d = dets + ((size_t)b * max_det + inst) * row;
-    if (tid < nm) coef[tid] = d[6 + tid];
+    const int tid = threadIdx.x;
+    const int tiles_x = (W + MT - 1) / MT, tiles_y = (H + MT - 1) / MT;
+    const int n = *nitems;
+    for (int it = blockIdx.x; it < n; it += gridDim.x) {
+        const int2 itm = items[it];
+        const int item = itm.x;
+        const int tx = item % tiles_x, ty = (item / tiles_x) % tiles_y, slot = item / (tiles_x * tiles_y);
+        const int b = itm.y >> 16, inst = itm.y & 0xffff;
+        __syncthreads();                  // previous iteration is done with the shared tiles
+        const int y0 = ty * MT, x0 = tx * MT;
+        const int row = 6 + nm;
+        const float* d = dets + ((size_t)b * max_det + inst) * row;
+        if (tid < nm) coef[tid] = d[6 + tid];
 
-    // torch: area_pixel_compute_scale<float>(in, out) = (float)in / out ; src = scale*(dst+0.5)-0.5, clamped at 0
-    const float sh = (float)Hp / (float)H, sw = (float)Wp / (float)W;
-    float fy0 = sh * ((float)y0 + 0.5f) - 0.5f; fy0 = fy0 < 0.f ? 0.f : fy0;
-    float fx0 = sw * ((float)x0 + 0.5f) - 0.5f; fx0 = fx0 < 0.f ? 0.f : fx0;
-    const int ly0 = (int)fy0, lx0 = (int)fx0;     // first low-res row/col this tile touches
-    // crop box in prototype pixels: boxes * (mw/iw) etc. in fp32 (torch multiplies an f32 tensor by a python float)
-    const float wr = (float)((double)Wp / (double)W), hr = (float)((double)Hp / (double)H);
-    const float bx1 = d[0] * wr, by1 = d[1] * hr, bx2 = d[2] * wr, by2 = d[3] * hr;
-    __syncthreads();
+        // torch: area_pixel_compute_scale<float>(in, out) = (float)in / out ; src = scale*(dst+0.5)-0.5, clamped at 0
+        const float sh = (float)Hp / (float)H, sw = (float)Wp / (float)W;
+        float fy0 = sh * ((float)y0 + 0.5f) - 0.5f; fy0 = fy0 < 0.f ? 0.f : fy0;
+        float fx0 = sw * ((float)x0 + 0.5f) - 0.5f; fx0 = fx0 < 0.f ? 0.f : fx0;
+        const int ly0 = (int)fy0, lx0 = (int)fx0;     // first low-res row/col this tile touches
+        // crop box in prototype pixels: boxes * (mw/iw) etc. in fp32 (torch multiplies an f32 tensor by a python float)
+        const float wr = (float)((double)Wp / (double)W), hr = (float)((double)Hp / (double)H);
+        const float bx1 = d[0] * wr, by1 = d[1] * hr, bx2 = d[2] * wr, by2 = d[3] * hr;
+        __syncthreads();
 
-    for (int e = tid; e < ML * ML; e += 256) {
-        const int r = e / ML, c = e - r * ML;
-        const int py = ly0 + r, px = lx0 + c;
-        float v = 0.f;
-        if (py < Hp && px < Wp) {
-            const float fr = (float)py, fc = (float)px;
-            if (fc >= bx1 && fc < bx2 && fr >= by1 && fr < by2) {
-                const T* pp = proto + ((size_t)(b * Hp + py) * Wp + px) * nm;
-                float acc = 0.f;
-                for (int k = 0; k < nm; ++k) acc += coef[k] * (float)pp[k];
-                v = mode == VTI_MASK_SIGMOID ? 1.0f / (1.0f + expf(-acc)) : acc;
-            }
-        }
-        low[r][c] = v;
-    }
-    __syncthreads();
-
-    const float thr = mode == VTI_MASK_SIGMOID ? 0.5f : 0.0f;
-    const int ry = tid >> 2, seg = (tid & 3) * 16;
-    const int y = y0 + ry;
-    if (y >= H) return;
-    float sy = sh * ((float)y + 0.5f) - 0.5f; sy = sy < 0.f ? 0.f : sy;
-    const int iy = (int)sy;
-    const int iy1 = iy + (iy < Hp - 1 ? 1 : 0);
-    const float ly1 = sy - (float)iy, lyw0 = 1.0f - ly1;
-    unsigned bits = 0;
-    unsigned wrd[4] = {0u, 0u, 0u, 0u};   // 16 mask bytes (0/1), little endian
+        for (int e = tid; e < ML * ML; e += 256) {
+            const int r = e / ML, c = e - r * ML;
+            const int py = ly0 + r, px = lx0 + c;
+            float v = 0.f;
+            if (py < Hp && px < Wp) {
+                const float fr = (float)py, fc = (float)px;
+                if (fc >= bx1 && fc < bx2 && fr >= by1 && fr < by2) {
+                    const T* pp = proto + ((size_t)(b * Hp + py) * Wp + px) * nm;
+                    float acc = 0.f;
+                    constexpr int PV = 16 / sizeof(T);          // 16-B pieces (nm % 4 == 0, rows 16-B aligned when nm % PV == 0)
+                    if (nm % PV == 0) {
+                        typedef T pvec __attribute__((ext_vector_type(PV)));
+                        for (int k = 0; k < nm; k += PV) {
+                            const pvec v = *(const pvec*)(pp + k);
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const int x = x0 + seg + j;
-        float sx = sw * ((float)x + 0.5f) - 0.5f; sx = sx < 0.f ? 0.f : sx;
-        const int ix = (int)sx;
-        const int ix1 = ix + (ix < Wp - 1 ? 1 : 0);
-        const float lx1 = sx - (float)ix, lxw0 = 1.0f - lx1;
-        bool on = false;
-        if (x < W) {
-            const float t0 = low[iy - ly0][ix - lx0] * lxw0 + low[iy - ly0][ix1 - lx0] * lx1;
-            const float t1 = low[iy1 - ly0][ix - lx0] * lxw0 + low[iy1 - ly0][ix1 - lx0] * lx1;
-            on = (t0 * lyw0 + t1 * ly1) > thr;
+                            for (int j = 0; j < PV; ++j) acc += coef[k + j] * (float)v[j];
+                        }
+                    } else {
+                        for (int k = 0; k < nm; ++k) acc += coef[k] * (float)pp[k];
+                    }
+                    v = mode == VTI_MASK_SIGMOID ? 1.0f / (1.0f + expf(-acc)) : acc;
+                }
+            }
+            low[r][c] = v;
         }
-        wrd[j >> 2] |= (on ? 1u : 0u) << ((j & 3) * 8);
-        bits |= (on ? 1u : 0u) << j;
-    }
-    if (packing == VTI_PACK_U8) {
-        uint8_t* o = masks + ((size_t)slot * H + y) * W + x0 + seg;
-        if (x0 + seg + 16 <= W && (W & 15) == 0) {
-            *(uint4*)o = make_uint4(wrd[0], wrd[1], wrd[2], wrd[3]);
+        __syncthreads();
+
+        const float thr = mode == VTI_MASK_SIGMOID ? 0.5f : 0.0f;
+        const int ry = tid >> 2, seg = (tid & 3) * 16;
+        const int y = y0 + ry;
+        if (y >= H) continue;
+        float sy = sh * ((float)y + 0.5f) - 0.5f; sy = sy < 0.f ? 0.f : sy;
+        const int iy = (int)sy;
+        const int iy1 = iy + (iy < Hp - 1 ? 1 : 0);
+        const float ly1 = sy - (float)iy, lyw0 = 1.0f - ly1;
+        unsigned bits = 0;
+        unsigned wrd[4] = {0u, 0u, 0u, 0u};   // 16 mask bytes (0/1), little endian
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int x = x0 + seg + j;
+            float sx = sw * ((float)x + 0.5f) - 0.5f; sx = sx < 0.f ? 0.f : sx;
+            const int ix = (int)sx;
+            const int ix1 = ix + (ix < Wp - 1 ? 1 : 0);
+            const float lx1 = sx - (float)ix, lxw0 = 1.0f - lx1;
+            bool on = false;
+            if (x < W) {
+                const float t0 = low[iy - ly0][ix - lx0] * lxw0 + low[iy - ly0][ix1 - lx0] * lx1;
+                const float t1 = low[iy1 - ly0][ix - lx0] * lxw0 + low[iy1 - ly0][ix1 - lx0] * lx1;
+                on = (t0 * lyw0 + t1 * ly1) > thr;
+            }
+            wrd[j >> 2] |= (on ? 1u : 0u) << ((j & 3) * 8);
+            bits |= (on ? 1u : 0u) << j;
+        }
+        if (packing == VTI_PACK_U8) {
+            uint8_t* o = masks + ((size_t)slot * H + y) * W + x0 + seg;
+            if (x0 + seg + 16 <= W && (W & 15) == 0) {
+                *(uint4*)o = make_uint4(wrd[0], wrd[1], wrd[2], wrd[3]);
+            } else {
+                for (int j = 0; j < 16 && x0 + seg + j < W; ++j) o[j] = (uint8_t)((bits >> j) & 1u);
+            }
         } else {
-            for (int j = 0; j < 16 && x0 + seg + j < W; ++j) o[j] = (uint8_t)((bits >> j) & 1u);
+            const int wb = W >> 3;   // W is a multiple of 32
+            uint8_t* o = masks + ((size_t)slot * H + y) * wb + ((x0 + seg) >> 3);
+            if (x0 + seg < W) o[0] = (uint8_t)(bits & 0xff);
+            if (x0 + seg + 8 < W) o[1] = (uint8_t)(bits >> 8);
         }
-    } else {
-        const int wb = W >> 3;   // W is a multiple of 32
-        uint8_t* o = masks + ((size_t)slot * H + y) * wb + ((x0 + seg) >> 3);
-        if (x0 + seg < W) o[0] = (uint8_t)(bits & 0xff);
-        if (x0 + seg + 8 < W) o[1] = (uint8_t)(bits >> 8);
     }
+}
+
+size_t masks_workspace_bytes(int capacity, int H, int W) {
+    const size_t tiles = (size_t)((H + MT - 1) / MT) * ((W + MT - 1) / MT);
+    return 256 + ((((size_t)capacity * tiles * 8) + 255) & ~(size_t)255);
 }
 
 hipError_t launch_masks(int dtype, const float* dets, const int* counts, const void* proto, int B, int max_det, int nm,
                         int Hp, int Wp, int H, int W, int mode, int packing, uint8_t* masks, int capacity,
-                        int* offsets, hipStream_t st) {
+                        int* offsets, void* ws, hipStream_t st) {
     if (B == 0) return hipSuccess;
     if (Hp * 4 != H || Wp * 4 != W || nm > 64) return hipErrorInvalidValue;   // tile geometry assumes stride-4 prototypes
-    hipLaunchKernelGGL(mask_offsets_kernel, dim3(1), dim3(64), 0, st, counts, B, max_det, offsets);
+    int* nitems = (int*)ws;
+    int2* items = (int2*)((char*)ws + 256);
+    if (max_det > 65535) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(mask_offsets_kernel, dim3(1), dim3(256), (size_t)(B + 1) * sizeof(int), st, counts, B, max_det, offsets, nitems);
     if (capacity <= 0) return hipGetLastError();
-    const int tiles = ((H + MT - 1) / MT) * ((W + MT - 1) / MT);
-    // grid.y is limited to 65535: loop in slabs
-    for (int s0 = 0; s0 < capacity; s0 += 65535) {
-        const int ns = capacity - s0 < 65535 ? capacity - s0 : 65535;
-        // slot index = blockIdx.y + s0 is folded in by offsetting the mask pointer and prefix comparison:
-        // keep it simple -- capacity above 65535 instances per call is rejected.
-        if (s0 > 0) return hipErrorInvalidValue;
-        if (dtype == VTI_F16)
-            hipLaunchKernelGGL(masks_kernel<half_t>, dim3(tiles, ns), dim3(256), 0, st, dets, offsets, (const half_t*)proto,
-                               B, max_det, nm, Hp, Wp, H, W, mode, packing, masks, capacity);
-        else
-            hipLaunchKernelGGL(masks_kernel<float>, dim3(tiles, ns), dim3(256), 0, st, dets, offsets, (const float*)proto,
-                               B, max_det, nm, Hp, Wp, H, W, mode, packing, masks, capacity);
-    }
+    hipLaunchKernelGGL(mask_plan_kernel, dim3((capacity + 255) / 256), dim3(256), 0, st, dets, offsets, B, max_det, 6 + nm, H, W,
+                       capacity, items, nitems);
+    const size_t out_bytes = (size_t)capacity * H * (packing == VTI_PACK_U8 ? W : W / 8);
+    hipError_t e = hipMemsetAsync(masks, 0, out_bytes, st);
+    if (e != hipSuccess) return e;
+    const int grid = 256 * 8;     // persistent blocks walk the work list
+    if (dtype == VTI_F16)
+        hipLaunchKernelGGL(masks_kernel<half_t>, dim3(grid), dim3(256), 0, st, dets, offsets, (const half_t*)proto, B, max_det, nm,
+                           Hp, Wp, H, W, mode, packing, masks, items, nitems);
+    else
+        hipLaunchKernelGGL(masks_kernel<float>, dim3(grid), dim3(256), 0, st, dets, offsets, (const float*)proto, B, max_det, nm,
+                           Hp, Wp, H, W, mode, packing, masks, items, nitems);
     return hipGetLastError();
 }
 

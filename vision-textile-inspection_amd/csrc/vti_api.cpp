@@ -29,6 +29,7 @@ struct vti_ctx {
 };
 
 static std::string g_create_err;
+static const int kMaskSlotsPerFrame = 512;   // mask work-list capacity: max_batch * 512 instances per call
 
 static int32_t fail(vti_ctx* c, int32_t code, const std::string& msg) {
     if (c) c->err = msg; else g_create_err = msg;
@@ -86,7 +87,9 @@ int64_t vti_fused_params(const vti_ctx* c) { return c ? c->plan.fused_params : 0
 int64_t vti_macs_per_frame(const vti_ctx* c) { return c ? c->plan.macs : 0; }
 int64_t vti_workspace_bytes(const vti_ctx* c) {
     if (!c) return 0;
-    return (int64_t)(c->plan.ws_bytes + nms_workspace_bytes(c->plan.desc.max_batch, c->plan.num_anchors));
+    const vti_desc& d = c->plan.desc;
+    return (int64_t)(c->plan.ws_bytes + nms_workspace_bytes(d.max_batch, c->plan.num_anchors) +
+                     masks_workspace_bytes(d.max_batch * kMaskSlotsPerFrame, d.H, d.W));
 }
 int32_t vti_num_launches(const vti_ctx* c) { return c ? (int32_t)c->plan.ops.size() : 0; }
 
@@ -174,8 +177,8 @@ static void fill_conv_params(ConvParams& p, const ConvRow& r, const ConvCfg& g, 
     const int ks = deconv ? 1 : r.k, st = deconv ? 1 : r.s;
     const unsigned PW = conv0 ? (unsigned)g.TW : (unsigned)((g.TW - 1) * st + ks);
     p.pw_magic = (unsigned)((0x100000000ull + PW - 1) / PW);
-    const unsigned RWB = (unsigned)(2 * g.TW + 1) * 3;
-    p.rw_magic = (unsigned)((0x100000000ull + RWB - 1) / RWB);
+    const unsigned RWD = ((unsigned)(2 * g.TW + 1) * 3 + 6) >> 2;      // stem: dwords per u8 patch row
+    p.rw_magic = (unsigned)((0x100000000ull + RWD - 1) / RWD);
     p.tw_magic = (unsigned)((0x100000000ull + (unsigned)g.TW - 1) / (unsigned)g.TW);
 }
 
@@ -265,10 +268,14 @@ int32_t vti_masks(vti_ctx* c, const float* dets, const int32_t* counts, const vo
         return fail(c, VTI_ERR_ARG, "vti_masks: bad argument");
     if ((mode != VTI_MASK_LOGIT && mode != VTI_MASK_SIGMOID) || (packing != VTI_PACK_U8 && packing != VTI_PACK_BITS))
         return fail(c, VTI_ERR_ARG, "vti_masks: bad mode/packing");
-    if (capacity > 65535) return fail(c, VTI_ERR_UNSUPPORTED, "vti_masks: capacity above 65535 instances per call");
     const vti_desc& d = c->plan.desc;
+    if (!c->ws) return fail(c, VTI_ERR_STATE, "vti_masks: workspace not set");
+    if (B > d.max_batch) return fail(c, VTI_ERR_ARG, "vti_masks: B out of range");
+    if (capacity > d.max_batch * kMaskSlotsPerFrame)
+        return fail(c, VTI_ERR_UNSUPPORTED, "vti_masks: capacity above max_batch*512 instances per call");
+    void* mws = c->ws + c->act_bytes + nms_workspace_bytes(d.max_batch, c->plan.num_anchors);
     VTI_HIP(c, launch_masks(d.dtype, dets, counts, proto, B, max_det, d.nm, d.H / 4, d.W / 4, d.H, d.W, mode, packing, masks,
-                            capacity, offsets, (hipStream_t)stream), "mask kernel");
+                            capacity, offsets, mws, (hipStream_t)stream), "mask kernel");
     return VTI_OK;
 }
 

@@ -122,7 +122,8 @@ hipError_t launch_nms(const float* pred, int B, int A, int nc, int nm, float con
                       int agnostic, float* dets, int* counts, void* ws, hipStream_t st);
 hipError_t launch_masks(int dtype, const float* dets, const int* counts, const void* proto, int B, int max_det,
                         int nm, int Hp, int Wp, int H, int W, int mode, int packing, uint8_t* masks,
-                        int capacity, int* offsets, hipStream_t st);
+                        int capacity, int* offsets, void* ws, hipStream_t st);
+size_t masks_workspace_bytes(int capacity, int H, int W);
 hipError_t launch_scale_boxes(const float* dets, const int* counts, int B, int max_det, int nm, int H, int W,
                               int H0, int W0, float* xyxy, hipStream_t st);
 hipError_t launch_mask_to_frame(const uint8_t* masks, int n, int H, int W, int H0, int W0, uint8_t* bitmaps,
