@@ -203,6 +203,14 @@ def main():
     flops_per_forward = 2.0 * eng.macs_per_frame * B
     achieved = flops_per_forward / (fwd_ms * 1e-3) / 1e12
 
+    # HBM bytes per forward from the committed rocprofv3 PMC passes (tools/make_profiles.sh): only
+    # valid for the configuration they were collected on.
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+    if os.path.exists(tpath) and B == 64 and args.dtype == "fp16":
+        fam = json.load(open(tpath))["families"]
+        traffic = sum(v["total_bytes"] for k, v in fam.items() if k.startswith("conv family") or k in ("decode_kernel", "sppf_pool", "upsample2x"))
+
     if rank == 0:
         line = {
             "metric": "frames/sec whole-node, YOLOv8n-seg 640x640 bs=64; mask IoU vs CPU ref",
@@ -215,7 +223,8 @@ def main():
                        "conf": CONF, "iou": IOU, "max_det": MAX_DET, "detections_per_frame": round(dets_per_frame, 2),
                        "mask_capacity_per_frame": SLOTS_PER_FRAME, "parallelism": f"dp{world}", "exchange": exch_note},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / MFMA_PEAK_TFLOPS, 5), "traffic": None,
+                         "frac": round(achieved / MFMA_PEAK_TFLOPS, 5), "traffic": traffic,
+                         "traffic_note": "HBM bytes per forward (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes, profiles/r01_hbm_traffic.json); algorithmic unfused activation bytes = 91.6 MB/frame",
                          "kernel": "vti::conv_kernel family (76 launches per forward) + pool/upsample/decode",
                          "flop_per_launch": flops_per_forward, "avg_ms": round(fwd_ms, 4)},
             "stage_ms": {"forward": round(fwd_ms, 4), "nms+masks+scale_boxes": round(post_ms, 4)},
