@@ -201,32 +201,40 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc)[
 
 
 // Register-staged operand prefetch: a thread owns up to AR input-patch pieces and BR weight pieces
-// (16 B each) of a chunk.  issue() only starts the global loads; commit() writes them to LDS.  The
-// next chunk is issued before the MFMA loop of the current one, so HBM/L2 latency hides under MFMA.
-template <typename T, int KS, int S, int NREP, int MODE>
+// (16 B each) of a chunk.  issue() only starts the loads; commit() writes them to LDS.  The next chunk is
+// issued before the MFMA loop of the current one, so HBM/L2 latency hides under MFMA.
+// Loads are raw buffer loads: 32-bit per-piece offsets computed once per tile, a scalar offset per chunk,
+// and the hardware range check returns zeros for halo pixels outside the image (offset 0xFFFFFFFF).
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+template <typename V> __device__ __forceinline__ V buf_load16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    return __builtin_bit_cast(V, v);
+}
+
+template <typename T, int KS, int S, int NREP, int WN>
 __global__ __launch_bounds__(256) void conv_kernel(const ConvParams p) {
     using vec = typename Tr<T>::vec;
     constexpr int VEC = Tr<T>::VEC, KC = Tr<T>::KC;
-    constexpr int TAPS = (MODE == 1) ? 1 : KS * KS;
-    constexpr int PAD = KS / 2;
-    constexpr int AR = (MODE == 1) ? 1 : (S == 2 ? 12 : 8);
-    constexpr int BR = (TAPS == 1) ? 5 : 12;
+    constexpr int TAPS = KS * KS, PAD = KS / 2;
+    constexpr int NTB = WN * NREP;
+    constexpr int AR = (S == 2 ? 12 : 8);
+    constexpr int BR = (NTB * TAPS * 64 + 255) / 256;
+    constexpr unsigned OOB = 0xFFFFFFFFu;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int WN = p.WN;
     const int wn = wave % WN, wm = wave / WN;
     int t = blockIdx.x;
     const int tx = t % p.tiles_x; t /= p.tiles_x;
     const int ty = t % p.tiles_y;
     const int b = t / p.tiles_y;
     const int oy0 = ty * p.TH, ox0 = tx * p.TW;
-    const int PH = patch_dim(p.TH, KS, S, MODE), PW = patch_dim(p.TW, KS, S, MODE);
+    const int PH = (p.TH - 1) * S + KS, PW = (p.TW - 1) * S + KS;
     const int npix = PH * PW;
     const int plane_bytes = ((npix + 15) & ~15) * 16;
     char* smA = smem;
     char* smB = smem + 4 * plane_bytes;
-    const int NTB = WN * NREP;
     const int nt0 = blockIdx.y * NTB;
     const int tile_px = p.TH * p.TW;
     VTI_STAMP(0);
@@ -242,8 +250,7 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvParams p) {
         const int py = (int)__umulhi((unsigned)pc, p.tw_magic), px = pc - py * p.TW;
         opy[m] = oy0 + py; opx[m] = ox0 + px;
         pvalid[m] = v && opy[m] < p.Hout && opx[m] < p.Wout;
-        const int lpix = (MODE == 1) ? pc : (py * S) * PW + px * S;
-        abase[m] = (lane >> 4) * plane_bytes + lpix * 16;
+        abase[m] = (lane >> 4) * plane_bytes + ((py * S) * PW + px * S) * 16;
     }
 
     f32x4 acc[MREP][NREP];
@@ -252,126 +259,87 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvParams p) {
 #pragma unroll
         for (int n = 0; n < NREP; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int iy0 = oy0 * S - PAD, ix0 = ox0 * S - PAD;
-    const int nitemA = npix * 4;
-    int ntv = p.ntiles_n - nt0;
-    ntv = ntv < NTB ? ntv : NTB;
-    const int nvalidB = ntv * TAPS * 64, ntotB = NTB * TAPS * 64;
+    // ---- operand sources as buffer resources (wave-uniform bases)
+    const size_t frame_elems = (size_t)p.Hin * p.Win * p.in_ld;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((const T*)p.in + (size_t)b * frame_elems), 0, (int)(frame_elems * sizeof(T)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.wpk, 0, (int)p.wpk_bytes, 0x00020000);
 
-    // per-thread source offsets of the A pieces are chunk-invariant: compute them once
-    // (element offset of the piece's first channel in chunk 0, or -1 for zero fill)
-    long aoff[AR];
-    if constexpr (MODE == 0) {
+    // item -> (pixel, 16-B channel piece q): 8 consecutive lanes take 8 consecutive pixels of ONE plane (a
+    // conflict-free 128-B ds_write run); a wave instruction still covers 16 pixels x 64 B of global memory.
+    // item i = tid + 256*u  ->  pixel = (tid>>5)*8 + (tid&7) + 64*u, q = (tid>>3)&3 (same q for every u).
+    const int iy0 = oy0 * S - PAD, ix0 = ox0 * S - PAD;
+    const int q = (tid >> 3) & 3;
+    const int pix0 = (tid >> 5) * 8 + (tid & 7);
+    const int ldsA0 = q * plane_bytes + pix0 * 16;          // + u * 1024 per piece
+    const int cvalid = (p.Cin - q * VEC + KC - 1) / KC;     // chunks in which this lane's channel piece exists
+    unsigned aoff[AR];
 #pragma unroll
-        for (int u = 0; u < AR; ++u) {
-            // item -> (pixel, 16-B channel piece q): 8 consecutive lanes take 8 consecutive pixels of ONE
-            // plane (a conflict-free 128-B ds_write run); a wave instruction still covers 16 pixels x 64 B
-            // of global memory, i.e. the same cache lines as a pixel-major order would.
-            const int i = tid + u * 256;
-            const int pix = (i >> 5) * 8 + (i & 7), q = (i >> 3) & 3;
-            const int py = (int)__umulhi((unsigned)pix, p.pw_magic), px = pix - py * PW;
-            const int y = iy0 + py, x = ix0 + px;
-            const bool ok = pix < npix && (unsigned)y < (unsigned)p.Hin && (unsigned)x < (unsigned)p.Win;
-            aoff[u] = ok ? (long)(((size_t)(b * p.Hin + y) * p.Win + x) * p.in_ld + p.in_coff + q * VEC) : -1;
-        }
+    for (int u = 0; u < AR; ++u) {
+        const int pix = pix0 + 64 * u;
+        const int py = (int)__umulhi((unsigned)pix, p.pw_magic), px = pix - py * PW;
+        const int y = iy0 + py, x = ix0 + px;
+        const bool ok = pix < npix && (unsigned)y < (unsigned)p.Hin && (unsigned)x < (unsigned)p.Win;
+        aoff[u] = ok ? (unsigned)(((y * p.Win + x) * p.in_ld + p.in_coff + q * VEC) * (int)sizeof(T)) : OOB;
     }
     vec ra[AR], rb[BR];
     auto issue = [&](int c) {
-        if constexpr (MODE == 0) {
-            const T* inb = (const T*)p.in;
+        const bool qok = c < cvalid;
 #pragma unroll
-            for (int u = 0; u < AR; ++u) {
+        for (int u = 0; u < AR; ++u)
+            if (pix0 + 64 * u < ((npix + 7) & ~7))
+                ra[u] = buf_load16<vec>(rsA, qok ? aoff[u] : OOB, (unsigned)(c * KC * (int)sizeof(T)));
+        const unsigned sB = (unsigned)(((size_t)c * p.ntiles_n + nt0) * (TAPS * 1024));
 #pragma unroll
-                for (int j = 0; j < VEC; ++j) ra[u][j] = 0;
-                if (aoff[u] >= 0 && c * KC + ((tid >> 3) & 3) * VEC < p.Cin) ra[u] = *(const vec*)(inb + aoff[u] + c * KC);
-            }
-        }
-        const vec* wsrc = (const vec*)p.wpk + ((size_t)c * p.ntiles_n + nt0) * (TAPS * 64);
-#pragma unroll
-        for (int u = 0; u < BR; ++u) {
-            const int i = tid + u * 256;
-#pragma unroll
-            for (int j = 0; j < VEC; ++j) rb[u][j] = 0;
-            if (i < nvalidB) rb[u] = wsrc[i];
-        }
+        for (int u = 0; u < BR; ++u)
+            if (tid + u * 256 < NTB * TAPS * 64) rb[u] = buf_load16<vec>(rsB, (unsigned)(tid + u * 256) * 16u, sB);
     };
-    auto commit = [&](int c) {
-        if constexpr (MODE == 0) {
+    auto commit = [&]() {
 #pragma unroll
-            for (int u = 0; u < AR; ++u) {
-                const int i = tid + u * 256;
-                const int pix = (i >> 5) * 8 + (i & 7), q = (i >> 3) & 3;
-                if (pix < npix) *(vec*)(smA + q * plane_bytes + pix * 16) = ra[u];
-            }
-        } else {
-            // conv0: im2col from the u8 patch staged in LDS: k = (kh*3+kw)*3 + channel, K = 27 -> 32
-            const int RWB = (2 * p.TW + 1) * 3;
-            const unsigned char* raw = (const unsigned char*)(smB + NTB * TAPS * 1024);
-            for (int i = tid; i < nitemA; i += 256) {
-                const int pix = i >> 2, q = i & 3;
-                const int py = (int)__umulhi((unsigned)pix, p.pw_magic), px = pix - py * PW;
-                vec v;
+        for (int u = 0; u < AR; ++u)
+            if (pix0 + 64 * u < npix) *(vec*)(smA + ldsA0 + u * 1024) = ra[u];
 #pragma unroll
-                for (int j = 0; j < VEC; ++j) {
-                    const int k = c * KC + q * VEC + j;
-                    float f = 0.f;
-                    if (k < 27) {
-                        const int tap = k / 3, chn = k - tap * 3;
-                        const int kh = tap / 3, kw = tap - kh * 3;
-                        const int cs = p.swap_rb ? 2 - chn : chn;
-                        // zero padding: out-of-image bytes were staged as 0 and 0/255 == 0
-                        f = (float)raw[(py * 2 + kh) * RWB + (px * 2 + kw) * 3 + cs] / 255.0f;
-                    }
-                    v[j] = (T)f;
-                }
-                *(vec*)(smA + q * plane_bytes + pix * 16) = v;
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < BR; ++u) {
-            const int i = tid + u * 256;
-            if (i < ntotB) ((vec*)smB)[i] = rb[u];
-        }
+        for (int u = 0; u < BR; ++u)
+            if (tid + u * 256 < NTB * TAPS * 64) *(vec*)(smB + (tid + u * 256) * 16) = rb[u];
     };
-
-    if constexpr (MODE == 1) {
-        // u8 frame patch (2*TH+1 x 2*TW+1 x 3 bytes) -> LDS with coalesced loads, zero outside the image
-        const uint8_t* inb = (const uint8_t*)p.in;
-        const int RH = 2 * p.TH + 1, RWB = (2 * p.TW + 1) * 3;
-        unsigned char* raw = (unsigned char*)(smB + NTB * TAPS * 1024);
-        const int y0 = oy0 * 2 - 1, x0b = (ox0 * 2 - 1) * 3;
-        for (int i = tid; i < RH * RWB; i += 256) {
-            const int ry = (int)__umulhi((unsigned)i, p.rw_magic), rx = i - ry * RWB;
-            const int y = y0 + ry, xb = x0b + rx;
-            unsigned char val = 0;
-            if ((unsigned)y < (unsigned)p.Hin && (unsigned)xb < (unsigned)(p.Win * 3))
-                val = inb[((size_t)(b * p.Hin + y) * p.Win) * 3 + xb];
-            raw[i] = val;
-        }
-        __syncthreads();
-    }
 
     issue(0);
     for (int c = 0; c < p.nchunks; ++c) {
         if (c < 2) VTI_STAMP(1 + 5 * c);
-        commit(c);                          // waits for this chunk's loads, fills LDS
+        commit();                           // waits for this chunk's loads, fills LDS
         if (c < 2) VTI_STAMP(3 + 5 * c);
         __syncthreads();
         if (c < 2) VTI_STAMP(4 + 5 * c);
         if (c + 1 < p.nchunks) issue(c + 1);   // in flight during the MFMA loop below
-        // ---- MFMA over the taps of this chunk
+        // ---- MFMA over the taps of this chunk, software pipelined over the flat (tap, pixel-tile)
+        // sequence: pixel fragments are read two steps ahead and the next tap's weight fragments one
+        // whole tap ahead, so LDS latency hides under the 4-5 MFMAs of each step.
+        {
+            constexpr int NSTEP = TAPS * MREP;
+            vec xq[3];
+            vec wq[2][NREP];
+            auto ldx = [&](int s_) -> vec {
+                const int tp = s_ / MREP, mm = s_ % MREP;
+                const int toff = ((tp / KS) * PW + (tp % KS)) * 16;
+                return *(const vec*)(smA + abase[mm] + toff);
+            };
+            auto ldw = [&](int tp, vec (&w)[NREP]) {
 #pragma unroll
-        for (int tap = 0; tap < TAPS; ++tap) {
-            const int toff = (MODE == 1) ? 0 : ((tap / KS) * PW + (tap % KS)) * 16;
-            vec w[NREP];
+                for (int n = 0; n < NREP; ++n)
+                    w[n] = *(const vec*)(smB + ((wn * NREP + n) * TAPS + tp) * 1024 + lane * 16);
+            };
+            ldw(0, wq[0]);
+            xq[0] = ldx(0);
+            if (NSTEP > 1) xq[1] = ldx(1);
 #pragma unroll
-            for (int n = 0; n < NREP; ++n)
-                w[n] = *(const vec*)(smB + ((size_t)((wn * NREP + n) * TAPS + tap) * 64 + lane) * 16);
+            for (int s_ = 0; s_ < NSTEP; ++s_) {
+                const int tp = s_ / MREP, mm = s_ % MREP;
+                if (s_ + 2 < NSTEP) xq[(s_ + 2) % 3] = ldx(s_ + 2);
+                if (mm == 0 && tp + 1 < TAPS) ldw(tp + 1, wq[(tp + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);      // keep the prefetch reads ahead of this step's MFMAs
 #pragma unroll
-            for (int m = 0; m < MREP; ++m) {
-                const vec x = *(const vec*)(smA + abase[m] + toff);
-#pragma unroll
-                for (int n = 0; n < NREP; ++n) acc[m][n] = mma(w[n], x, acc[m][n]);
+                for (int n = 0; n < NREP; ++n) acc[mm][n] = mma(wq[tp & 1][n], xq[s_ % 3], acc[mm][n]);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         if (c < 2) VTI_STAMP(5 + 5 * c);
@@ -481,32 +449,33 @@ size_t stem_lds_bytes(int TH, int TW) { return 1024 + (size_t)(2 * TH + 1) * (((
 // Host-side check that a geometry fits the kernel's fixed register staging arrays.
 bool conv_cfg_fits(int ks, int stride, int mode, int TH, int TW, int WN, int NREP) {
     if (mode == 1) return WN == 1 && (2 * TH + 1) * (((2 * TW + 1) * 3 + 6) >> 2) < 65536;
-    const int taps = mode == 1 ? 1 : ks * ks;
-    const int AR = mode == 1 ? 1 : (stride == 2 ? 12 : 8), BR = taps == 1 ? 5 : 12;
+    const int AR = stride == 2 ? 12 : 8;
     const int npix = patch_dim(TH, ks, stride, mode) * patch_dim(TW, ks, stride, mode);
-    if (mode == 0 && ((npix + 7) / 8) * 32 > 256 * AR) return false;
-    return WN * NREP * taps * 64 <= 256 * BR;
+    if (((npix + 7) / 8) * 32 > 256 * AR) return false;     // input pieces per thread
+    return ks == 1 || WN * NREP <= 5;                        // 3x3 instantiations cover WN*NREP <= 5
 }
 
-template <typename T, int KS, int S, int MODE>
-static hipError_t launch_nrep(int nrep, const ConvParams& p, dim3 grid, size_t lds, hipStream_t st) {
-#define VTI_LAUNCH(N)                                                                         \
-    case N: {                                                                                 \
-        auto k = conv_kernel<T, KS, S, N, MODE>;                                              \
-        static size_t lds_ok = 64 * 1024;                                                     \
-        if (lds > lds_ok) {                                                                   \
-            hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-            if (e != hipSuccess) return e;                                                    \
-            lds_ok = 160 * 1024;                                                              \
-        }                                                                                     \
-        hipLaunchKernelGGL(k, grid, dim3(256), lds, st, p);                                   \
-        return hipGetLastError();                                                             \
+template <typename T, int KS, int S, int NREP, int WN>
+static hipError_t launch_one(const ConvParams& p, dim3 grid, size_t lds, hipStream_t st) {
+    auto k = conv_kernel<T, KS, S, NREP, WN>;
+    static size_t lds_ok = 64 * 1024;
+    if (lds > lds_ok) {
+        hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        lds_ok = 160 * 1024;
     }
-    switch (nrep) {
-        VTI_LAUNCH(1) VTI_LAUNCH(2) VTI_LAUNCH(3) VTI_LAUNCH(4) VTI_LAUNCH(5)
-        default: return hipErrorInvalidValue;
-    }
-#undef VTI_LAUNCH
+    hipLaunchKernelGGL(k, grid, dim3(256), lds, st, p);
+    return hipGetLastError();
+}
+
+// 3x3 kernels exist for WN*NREP <= 5 (the weight prefetch array is sized by it); 1x1 for every split.
+template <typename T, int KS, int S>
+static hipError_t launch_ks(int nrep, int wn, const ConvParams& p, dim3 grid, size_t lds, hipStream_t st) {
+#define VTI_L(N, W) if (nrep == N && wn == W) return launch_one<T, KS, S, N, W>(p, grid, lds, st);
+    VTI_L(1, 1) VTI_L(2, 1) VTI_L(3, 1) VTI_L(4, 1) VTI_L(5, 1) VTI_L(1, 2) VTI_L(2, 2) VTI_L(1, 4)
+    if constexpr (KS == 1) { VTI_L(3, 2) VTI_L(4, 2) VTI_L(5, 2) VTI_L(2, 4) VTI_L(3, 4) VTI_L(4, 4) VTI_L(5, 4) }
+#undef VTI_L
+    return hipErrorInvalidValue;
 }
 
 template <typename T>
@@ -520,9 +489,9 @@ static hipError_t launch_t(int ks, int stride, int nrep, int mode, const ConvPar
             default: return hipErrorInvalidValue;
         }
     }
-    if (ks == 1 && stride == 1) return launch_nrep<T, 1, 1, 0>(nrep, p, grid, lds, st);
-    if (ks == 3 && stride == 1) return launch_nrep<T, 3, 1, 0>(nrep, p, grid, lds, st);
-    if (ks == 3 && stride == 2) return launch_nrep<T, 3, 2, 0>(nrep, p, grid, lds, st);
+    if (ks == 1 && stride == 1) return launch_ks<T, 1, 1>(nrep, p.WN, p, grid, lds, st);
+    if (ks == 3 && stride == 1) return launch_ks<T, 3, 1>(nrep, p.WN, p, grid, lds, st);
+    if (ks == 3 && stride == 2) return launch_ks<T, 3, 2>(nrep, p.WN, p, grid, lds, st);
     return hipErrorInvalidValue;
 }
 

@@ -180,6 +180,7 @@ static void fill_conv_params(ConvParams& p, const ConvRow& r, const ConvCfg& g, 
     const unsigned RWD = ((unsigned)(2 * g.TW + 1) * 3 + 6) >> 2;      // stem: dwords per u8 patch row
     p.rw_magic = (unsigned)((0x100000000ull + RWD - 1) / RWD);
     p.tw_magic = (unsigned)((0x100000000ull + (unsigned)g.TW - 1) / (unsigned)g.TW);
+    p.wpk_bytes = (unsigned)packed_conv_bytes(r, conv0, g);
 }
 
 int32_t vti_forward(vti_ctx* c, const uint8_t* input, int32_t B, int32_t swap_rb, float* pred, void* proto, void* stream) {

@@ -88,6 +88,7 @@ struct ConvParams {
     int TH, TW, tiles_y, tiles_x, WN;
     int act, out_f32, deconv_c, swap_rb, nchunks, ntiles_n, has_res, scalar_store;
     unsigned pw_magic, rw_magic, tw_magic;   // ceil(2^32 / {PW, raw-row-bytes, TW}): division-free indexing
+    unsigned wpk_bytes;                  // bytes of this conv's packed weights (buffer-load range check)
     unsigned long long* stamps;          // diagnostic build only (VTI_STAMPS): 16 s_memtime slots per workgroup
 };
 
