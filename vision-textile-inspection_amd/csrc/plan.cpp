@@ -28,7 +28,9 @@ int py_round(double x) { return (int)std::nearbyint(x); }
 struct Builder {
     Plan& P;
     int maxB;
-    explicit Builder(Plan& p) : P(p), maxB(p.desc.max_batch) {}
+    std::vector<Op>* cur;      // op group being filled (groups are ordered/laned at the end of build)
+    int lane = 0;
+    explicit Builder(Plan& p) : P(p), maxB(p.desc.max_batch), cur(&p.ops) {}
 
     int new_buf(int C, int H, int W, int elem = EL_T) {
         Buf b;
@@ -57,7 +59,8 @@ struct Builder {
         op.conv = (int)P.convs.size() - 1;
         op.in = in; op.out = out; op.out_f32 = out_f32;
         if (res) { op.res = *res; op.has_res = true; }
-        P.ops.push_back(op);
+        op.lane = lane;
+        cur->push_back(op);
     }
 
     // C2f(c1, c2, n, shortcut): cv1 -> 2c; n x Bottleneck(c, c, 3x3, 3x3) chained on the last
@@ -82,8 +85,8 @@ struct Builder {
     }
 
     void up2(View in, View out) {
-        Op op; op.kind = OP_UP2; op.in = in; op.out = out;
-        P.ops.push_back(op);
+        Op op; op.kind = OP_UP2; op.in = in; op.out = out; op.lane = lane;
+        cur->push_back(op);
     }
 };
 
@@ -133,6 +136,7 @@ void choose_conv_cfg(int dtype, const ConvRow& r, bool conv0, int max_batch, Con
                 const double rowb = std::min(1.0, (double)TW * 64.0 / 1024.0);
                 double score = m_eff * n_eff * (0.6 + 0.4 * halo) * (0.8 + 0.2 * rowb) / (0.35 + lds_traffic);
                 if (lds > 64 * 1024) score *= 0.9;
+                if (ks == 1 && WN >= 2) score *= 1.12;      // measured: 1x1 / deconv prefer more, smaller workgroups
                 const double wgs = (double)tiles * gy * max_batch;
                 if (wgs < 512) score *= 0.5 + 0.5 * wgs / 512;
                 if (score > best) {
@@ -168,6 +172,11 @@ std::string Plan::build(const vti_desc& d) {
         if (c % 16) return "channel count not a multiple of 16 for this scale";
 
     Builder b(*this);
+    // Op groups.  Frames are independent and so are the branches that hang off P3/P4/P5: the proto chain
+    // and the three head levels run on side streams (lanes) forked when their input is ready and joined
+    // before the decode, so the many small 40x40 / 20x20 kernels overlap instead of queueing.
+    std::vector<Op> g_p3, g_proto, g_head[3], g_p4, g_p5;
+    b.cur = &g_p3;
     const int H = d.H, W = d.W;
     const int in_u8 = b.new_buf(3, H, W, EL_U8);         // caller's letterboxed frames (not in workspace)
     const int B0 = b.new_buf(c0, H / 2, W / 2);
@@ -200,7 +209,7 @@ std::string Plan::build(const vti_desc& d) {
     // SPPF
     const View x9 = b.slice(CAT20, c3, c4);
     b.conv("model.9.cv1", b.whole(B8), b.slice(SP, 0, c4 / 2), 1, 1, 0);
-    { Op op; op.kind = OP_POOL; op.in = b.slice(SP, 0, c4 / 2); op.out = b.slice(SP, c4 / 2, 3 * (c4 / 2)); ops.push_back(op); }
+    { Op op; op.kind = OP_POOL; op.in = b.slice(SP, 0, c4 / 2); op.out = b.slice(SP, c4 / 2, 3 * (c4 / 2)); b.cur->push_back(op); }
     b.conv("model.9.cv2", b.whole(SP), x9, 1, 1, 0);
     // neck
     b.up2(x9, b.slice(CAT11, 0, c4));
@@ -208,15 +217,20 @@ std::string Plan::build(const vti_desc& d) {
     b.c2f(12, b.whole(CAT11), x12, rn, false);
     b.up2(x12, b.slice(CAT14, 0, c3));
     b.c2f(15, b.whole(CAT14), b.whole(P3), rn, false);
+    b.cur = &g_p4;
     b.conv("model.16", b.whole(P3), b.slice(CAT17, 0, c2), 3, 2, 0);
     b.c2f(18, b.whole(CAT17), b.whole(P4), rn, false);
+    b.cur = &g_p5;
     b.conv("model.19", b.whole(P4), b.slice(CAT20, 0, c3), 3, 2, 0);
     b.c2f(21, b.whole(CAT20), b.whole(P5), rn, false);
     // Segment head
     const int feat[3] = {P3, P4, P5};
     const int strides[3] = {8, 16, 32};
     num_anchors = 0;
+    const int head_lane[3] = {2, 3, 0};
     for (int l = 0; l < 3; ++l) {
+        b.cur = &g_head[l];
+        b.lane = head_lane[l];
         const Buf fb = bufs[feat[l]];
         Level lv; lv.C = fb.C; lv.H = fb.H; lv.W = fb.W; lv.stride = strides[l];
         const char* towers[3] = {"cv2", "cv3", "cv4"};
@@ -238,6 +252,8 @@ std::string Plan::build(const vti_desc& d) {
         levels.push_back(lv);
         num_anchors += fb.H * fb.W;
     }
+    b.cur = &g_proto;
+    b.lane = 1;
     {
         const int pc1 = b.new_buf(npr, H / 8, W / 8), pup = b.new_buf(npr, H / 4, W / 4);
         const int pc2 = b.new_buf(npr, H / 4, W / 4), pout = b.new_buf(d.nm, H / 4, W / 4);
@@ -247,7 +263,20 @@ std::string Plan::build(const vti_desc& d) {
         b.conv("model.22.proto.cv3", b.whole(pc2), b.whole(pout), 1, 1, 0);
         proto_buf_c = pout;   // replaced by the caller's proto pointer at run time
     }
-    { Op op; op.kind = OP_DECODE; ops.push_back(op); }
+    {   // final op order: lane 0 carries backbone + neck (+ the P5 head); side lanes fork off it
+        auto sync = [&](OpKind k, int lane) { Op op; op.kind = k; op.lane = lane; ops.push_back(op); };
+        auto add = [&](const std::vector<Op>& g) { ops.insert(ops.end(), g.begin(), g.end()); };
+        add(g_p3);
+        sync(OP_FORK, 1); sync(OP_FORK, 2);
+        add(g_proto); add(g_head[0]);
+        add(g_p4);
+        sync(OP_FORK, 3);
+        add(g_head[1]);
+        add(g_p5);
+        add(g_head[2]);
+        sync(OP_JOIN, 1); sync(OP_JOIN, 2); sync(OP_JOIN, 3);
+        Op op; op.kind = OP_DECODE; ops.push_back(op);
+    }
 
     // workspace layout: plain bump allocation, 256-B aligned; buffer 0 (u8 input) and the
     // proto output belong to the caller.

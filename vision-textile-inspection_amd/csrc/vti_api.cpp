@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -26,6 +27,11 @@ struct vti_ctx {
     size_t act_bytes = 0;      // activations part; NMS scratch follows
     const void* last_input = nullptr;
     void* last_proto = nullptr;
+    // side streams for the independent branches (proto chain, head levels); created with the weights
+    hipStream_t side[kNumLanes] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork[kNumLanes] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_join[kNumLanes] = {nullptr, nullptr, nullptr, nullptr};
+    bool multi_stream = false;
 };
 
 static std::string g_create_err;
@@ -59,6 +65,11 @@ void vti_destroy(vti_ctx* c) {
     if (!c) return;
     if (c->d_wpk) (void)hipFree(c->d_wpk);
     if (c->d_bias) (void)hipFree(c->d_bias);
+    for (int l = 1; l < kNumLanes; ++l) {
+        if (c->side[l]) (void)hipStreamDestroy(c->side[l]);
+        if (c->ev_fork[l]) (void)hipEventDestroy(c->ev_fork[l]);
+        if (c->ev_join[l]) (void)hipEventDestroy(c->ev_join[l]);
+    }
     delete c;
 }
 
@@ -91,7 +102,12 @@ int64_t vti_workspace_bytes(const vti_ctx* c) {
     return (int64_t)(c->plan.ws_bytes + nms_workspace_bytes(d.max_batch, c->plan.num_anchors) +
                      masks_workspace_bytes(d.max_batch * kMaskSlotsPerFrame, d.H, d.W));
 }
-int32_t vti_num_launches(const vti_ctx* c) { return c ? (int32_t)c->plan.ops.size() : 0; }
+int32_t vti_num_launches(const vti_ctx* c) {
+    if (!c) return 0;
+    int32_t n = 0;
+    for (const Op& op : c->plan.ops) n += (op.kind != OP_FORK && op.kind != OP_JOIN);
+    return n;
+}
 
 int32_t vti_load_weights(vti_ctx* c, const void* blob, size_t nbytes, int32_t device) {
     if (!c) return VTI_ERR_ARG;
@@ -108,6 +124,17 @@ int32_t vti_load_weights(vti_ctx* c, const void* blob, size_t nbytes, int32_t de
     VTI_HIP(c, hipMemcpy(c->d_wpk, wpk.data(), wpk.size(), hipMemcpyHostToDevice), "hipMemcpy(weights)");
     VTI_HIP(c, hipMemcpy(c->d_bias, bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice), "hipMemcpy(bias)");
     c->device = device;
+    // side streams (VTI_SINGLE_STREAM=1 keeps everything on the caller's stream)
+    const char* ss = getenv("VTI_SINGLE_STREAM");
+    if (!(ss && ss[0] == '1') && !c->side[1]) {
+        bool ok = true;
+        for (int l = 1; l < kNumLanes && ok; ++l) {
+            ok = hipStreamCreateWithFlags(&c->side[l], hipStreamNonBlocking) == hipSuccess &&
+                 hipEventCreateWithFlags(&c->ev_fork[l], hipEventDisableTiming) == hipSuccess &&
+                 hipEventCreateWithFlags(&c->ev_join[l], hipEventDisableTiming) == hipSuccess;
+        }
+        c->multi_stream = ok;
+    }
     return VTI_OK;
 }
 
@@ -189,10 +216,23 @@ int32_t vti_forward(vti_ctx* c, const uint8_t* input, int32_t B, int32_t swap_rb
     if (!input || !pred || !proto) return fail(c, VTI_ERR_ARG, "vti_forward: null pointer");
     if (B == 0) return VTI_OK;
     const Plan& P = c->plan;
-    hipStream_t st = (hipStream_t)stream;
+    hipStream_t main_st = (hipStream_t)stream;
     const int dt = P.desc.dtype;
     for (const Op& op : P.ops) {
+        hipStream_t st = (c->multi_stream && op.lane > 0) ? c->side[op.lane] : main_st;
         switch (op.kind) {
+        case OP_FORK:
+            if (c->multi_stream) {
+                VTI_HIP(c, hipEventRecord(c->ev_fork[op.lane], main_st), "fork record");
+                VTI_HIP(c, hipStreamWaitEvent(c->side[op.lane], c->ev_fork[op.lane], 0), "fork wait");
+            }
+            break;
+        case OP_JOIN:
+            if (c->multi_stream) {
+                VTI_HIP(c, hipEventRecord(c->ev_join[op.lane], c->side[op.lane]), "join record");
+                VTI_HIP(c, hipStreamWaitEvent(main_st, c->ev_join[op.lane], 0), "join wait");
+            }
+            break;
         case OP_CONV0:
         case OP_CONV: {
             const ConvRow& r = P.convs[op.conv];

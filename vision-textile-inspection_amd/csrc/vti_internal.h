@@ -36,7 +36,8 @@ struct ConvRow {         // fused conv table, Ultralytics order (SURVEY.md Appen
     int64_t fused_params() const { return (int64_t)c1 * c2 * k * k + c2; }
 };
 
-enum OpKind { OP_CONV0, OP_CONV, OP_POOL, OP_UP2, OP_DECODE };
+enum OpKind { OP_CONV0, OP_CONV, OP_POOL, OP_UP2, OP_DECODE, OP_FORK, OP_JOIN };
+constexpr int kNumLanes = 4;          // lane 0 = the caller's stream; 1..3 = ctx-owned side streams
 
 struct ConvCfg {         // launch geometry chosen at plan time
     int TH = 0, TW = 0;  // output tile (pixels)
@@ -56,6 +57,7 @@ struct Op {
     View in, out, res;
     bool has_res = false;
     bool out_f32 = false;
+    int lane = 0;        // stream the op is enqueued on (OP_FORK/OP_JOIN: the side lane that starts/finishes)
     ConvCfg cfg;
 };
 
