@@ -81,7 +81,8 @@ typedef struct {
     int64_t macs;                /* multiply-accumulates per frame */
     int32_t tile_h, tile_w;      /* launch geometry: output pixels per workgroup tile */
     int32_t waves_n, nrep;       /* waves along Cout, 16-wide cout tiles per wave */
-    int32_t lds_bytes, reserved;
+    int32_t lds_bytes;
+    int32_t fused;               /* 1: this 1x1 conv runs inside the previous conv's kernel (register-level fusion) */
 } vti_conv_info;
 
 /* ---- lifetime -------------------------------------------------------------------- */

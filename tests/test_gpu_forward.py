@@ -34,12 +34,23 @@ def test_layerwise_parity(scale, nc, H, W, B, dtype, tol):
     pred, proto = eng.forward(torch.from_numpy(fr).cuda(), swap_rb=True)
     torch.cuda.synchronize()
     opred, oproto = om.forward_u8(fr, swap_rb=True, record=True)
-    for i, t in enumerate(eng.conv_table()):
+    import vti_amd
+    checked = 0
+    table = eng.conv_table()
+    for i, t in enumerate(table):
+        if i + 1 < len(table) and table[i + 1]["fused"]:
+            # this 3x3's output feeds a 1x1 fused into its epilogue and never reaches memory;
+            # it is verified through that 1x1's output (next row)
+            with pytest.raises(vti_amd.VtiError):
+                eng.debug_conv_output(i, B)
+            continue
+        checked += 1
         got = eng.debug_conv_output(i, B).cpu()
         ref = om.taps[t["name"]]
         assert got.shape == ref.shape and torch.isfinite(ref).all(), t["name"]
         err = (got - ref).abs().max().item()
         assert err <= tol * max(ref.abs().max().item(), 1.0), f"{t['name']}: max|d|={err:.3e} ref max={ref.abs().max():.3e}"
+    assert checked >= len(table) - 10
     assert pred.shape == opred.shape and torch.isfinite(pred).all()
     if scale != "n":
         return      # m/s random nets carry |logit| ~ 100: only the per-layer bound above is meaningful there

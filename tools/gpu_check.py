@@ -23,7 +23,11 @@ def check(dtype, B=2, scale="n", nc=80, H=640, W=640, cls_bias=-2.0):
     print(f"[{dtype}] oracle forward {time.time()-t0:.2f}s")
     worst = 0
     for i, t in enumerate(eng.conv_table()):
-        got = eng.debug_conv_output(i, B).cpu()
+        try:
+            got = eng.debug_conv_output(i, B).cpu()
+        except vti_amd.VtiError:
+            print(f"  {i:2d} {t['name']:26s} (fused into the next conv; not materialised)")
+            continue
         ref = om.taps[t["name"]]
         err = (got - ref).abs().max().item()
         den = ref.abs().max().item() + 1e-9

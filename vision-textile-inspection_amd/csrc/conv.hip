@@ -212,7 +212,7 @@ template <typename V> __device__ __forceinline__ V buf_load16(__amdgpu_buffer_rs
     return __builtin_bit_cast(V, v);
 }
 
-template <typename T, int KS, int S, int NREP, int WN>
+template <typename T, int KS, int S, int NREP, int WN, int NREP2 = 0>
 __global__ __launch_bounds__(256) void conv_kernel(const ConvParams p) {
     using vec = typename Tr<T>::vec;
     constexpr int VEC = Tr<T>::VEC, KC = Tr<T>::KC;
@@ -347,7 +347,98 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvParams p) {
     }
 
     VTI_STAMP(11);
-    conv_epilogue<T, NREP>(p, acc, pvalid, opy, opx, b, nt0, wn, lane);
+    if constexpr (NREP2 == 0) {
+        conv_epilogue<T, NREP>(p, acc, pvalid, opy, opx, b, nt0, wn, lane);
+    } else {
+        // ---- fused 1x1 second stage on the register tile (WN == 1: this wave holds every mid channel
+        // of its 80 pixels).  silu(acc + bias) in fp16/fp32 IS the MFMA pixel operand of the next GEMM:
+        // lane group g of cout tile n holds channels 16n+4g+j, and the stage-2 weights are packed with
+        // exactly that K order (weights.cpp: pack_conv_stage2), so nothing moves between lanes or LDS.
+        static_assert(WN == 1, "fused stage needs the whole Cout in one wave");
+        constexpr bool FAST = sizeof(T) == 2;
+        constexpr int KT = sizeof(T) == 2 ? (NREP + 1) / 2 : NREP;
+        const __amdgpu_buffer_rsrc_t rsW2 = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)p.w2, 0, (int)(KT * p.ntiles2 * 1024), 0x00020000);
+        f32x4 bias1[NREP];
+#pragma unroll
+        for (int n = 0; n < NREP; ++n) bias1[n] = *(const f32x4*)(p.bias + n * 16 + (lane >> 4) * 4);
+        f32x4 acc2[MREP][NREP2];
+#pragma unroll
+        for (int m = 0; m < MREP; ++m)
+#pragma unroll
+            for (int n = 0; n < NREP2; ++n) acc2[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t2 = 0; t2 < KT; ++t2) {
+            vec w2[NREP2];
+#pragma unroll
+            for (int n = 0; n < NREP2; ++n)
+                w2[n] = buf_load16<vec>(rsW2, (unsigned)(((t2 * p.ntiles2 + n) * 64 + lane) * 16), 0u);
+#pragma unroll
+            for (int m = 0; m < MREP; ++m) {
+                vec x;
+                if constexpr (sizeof(T) == 2) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int n1 = 2 * t2 + h;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            float v = 0.f;
+                            if (n1 < NREP) {
+                                v = acc[m][n1 < NREP ? n1 : 0][j] + bias1[n1 < NREP ? n1 : 0][j];
+                                if (p.act) v = silu<FAST>(v);
+                            }
+                            x[h * 4 + j] = (T)v;
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float v = acc[m][t2][j] + bias1[t2][j];
+                        if (p.act) v = silu<FAST>(v);
+                        x[j] = v;
+                    }
+                }
+#pragma unroll
+                for (int n = 0; n < NREP2; ++n) acc2[m][n] = mma(w2[n], x, acc2[m][n]);
+            }
+        }
+        // second-stage epilogue: bias2 (+SiLU for proto.cv3), T or fp32 output
+        f32x4 bias2[NREP2];
+#pragma unroll
+        for (int n = 0; n < NREP2; ++n) bias2[n] = *(const f32x4*)(p.bias2 + n * 16 + (lane >> 4) * 4);
+#pragma unroll
+        for (int m = 0; m < MREP; ++m) {
+            if (!pvalid[m]) continue;
+            const size_t o0 = (((size_t)(b * p.Hout + opy[m])) * p.Wout + opx[m]) * p.out2_ld + p.out2_coff;
+#pragma unroll
+            for (int n = 0; n < NREP2; ++n) {
+                const int cout0 = n * 16 + (lane >> 4) * 4;
+                if (cout0 >= p.Cout2) continue;
+                f32x4 v = acc2[m][n] + bias2[n];
+                if (p.act2) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = silu<FAST>(v[j]);
+                }
+                const size_t o = o0 + cout0;
+                if (p.scalar_store2) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (cout0 + j < p.Cout2) {
+                            if (p.out2_f32) ((float*)p.out2)[o + j] = v[j];
+                            else ((T*)p.out2)[o + j] = (T)v[j];
+                        }
+                    }
+                } else if (p.out2_f32 || sizeof(T) == 4) {
+                    *(f32x4*)((float*)p.out2 + o) = v;
+                } else {
+                    half4 hv;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) hv[j] = (half_t)v[j];
+                    *(half4*)((half_t*)p.out2 + o) = hv;
+                }
+            }
+        }
+    }
     VTI_STAMP(12);
 }
 
@@ -455,9 +546,9 @@ bool conv_cfg_fits(int ks, int stride, int mode, int TH, int TW, int WN, int NRE
     return ks == 1 || WN * NREP <= 5;                        // 3x3 instantiations cover WN*NREP <= 5
 }
 
-template <typename T, int KS, int S, int NREP, int WN>
+template <typename T, int KS, int S, int NREP, int WN, int NREP2 = 0>
 static hipError_t launch_one(const ConvParams& p, dim3 grid, size_t lds, hipStream_t st) {
-    auto k = conv_kernel<T, KS, S, NREP, WN>;
+    auto k = conv_kernel<T, KS, S, NREP, WN, NREP2>;
     static size_t lds_ok = 64 * 1024;
     if (lds > lds_ok) {
         hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -478,9 +569,27 @@ static hipError_t launch_ks(int nrep, int wn, const ConvParams& p, dim3 grid, si
     return hipErrorInvalidValue;
 }
 
+// (3x3 s1, NREP mid tiles) + fused (1x1, NREP2 out tiles): the pairs YOLOv8-seg's heads / proto need
+bool conv_fusable(int nrep, int nrep2) {
+    return (nrep == 2 && nrep2 == 2) || (nrep == 3 && nrep2 == 2) || (nrep == 4 && (nrep2 == 1 || nrep2 == 2 || nrep2 == 4)) ||
+           (nrep == 5 && nrep2 == 5) || (nrep == 4 && nrep2 == 5);
+}
+
+template <typename T>
+static hipError_t launch_fused(int nrep, int nrep2, const ConvParams& p, dim3 grid, size_t lds, hipStream_t st) {
+#define VTI_F(N, N2) if (nrep == N && nrep2 == N2) return launch_one<T, 3, 1, N, 1, N2>(p, grid, lds, st);
+    VTI_F(2, 2) VTI_F(3, 2) VTI_F(4, 1) VTI_F(4, 2) VTI_F(4, 4) VTI_F(4, 5) VTI_F(5, 5)
+#undef VTI_F
+    return hipErrorInvalidValue;
+}
+
 template <typename T>
 static hipError_t launch_t(int ks, int stride, int nrep, int mode, const ConvParams& p, dim3 grid, size_t lds,
                            hipStream_t st) {
+    if (p.ntiles2 > 0) {
+        if (!(ks == 3 && stride == 1 && p.WN == 1 && mode == 0)) return hipErrorInvalidValue;
+        return launch_fused<T>(nrep, p.ntiles2, p, grid, lds, st);
+    }
     if (mode == 1) {
         switch (nrep) {
 #define VTI_STEM(N) case N: hipLaunchKernelGGL((stem_kernel<T, N>), grid, dim3(256), lds, st, p); return hipGetLastError();

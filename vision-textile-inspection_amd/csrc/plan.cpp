@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "vti_internal.h"
@@ -288,6 +289,31 @@ std::string Plan::build(const vti_desc& d) {
     }
     ws_bytes = off;
 
+    // fuse "3x3 conv -> 1x1 conv" pairs (head towers .1 -> .2, proto cv2 -> cv3): the 1x1 runs on the
+    // producer's register tile, its op disappears and the intermediate never reaches HBM.
+    {
+        const char* nf = getenv("VTI_NO_FUSE");
+        for (size_t i = 0; !(nf && nf[0] == '1') && i + 1 < ops.size(); ++i) {
+            Op& a = ops[i];
+            const Op& b2 = ops[i + 1];
+            if (a.kind != OP_CONV || b2.kind != OP_CONV || a.lane != b2.lane) continue;
+            const ConvRow& ra = convs[a.conv];
+            const ConvRow& rb = convs[b2.conv];
+            if (!(ra.k == 3 && ra.s == 1 && ra.kind == 0 && rb.k == 1 && rb.s == 1 && rb.kind != 2)) continue;
+            if (a.has_res || b2.has_res || a.out_f32) continue;
+            if (b2.in.buf != a.out.buf || b2.in.coff != a.out.coff || b2.in.C != a.out.C || a.out.C != bufs[a.out.buf].C) continue;
+            if (ra.c2 % 16 || !conv_fusable(ra.c2 / 16, (rb.c2 + 15) / 16)) continue;
+            bool other_reader = false;          // the intermediate must have no other consumer
+            for (size_t j = 0; j < ops.size(); ++j)
+                if (j != i + 1 && (ops[j].kind == OP_CONV || ops[j].kind == OP_UP2 || ops[j].kind == OP_POOL) &&
+                    (ops[j].in.buf == a.out.buf || (ops[j].has_res && ops[j].res.buf == a.out.buf))) other_reader = true;
+            if (other_reader) continue;
+            a.fused = b2.conv; a.out2 = b2.out; a.out2_f32 = b2.out_f32;
+            conv_out[a.conv].buf = -1;          // not materialised any more
+            ops.erase(ops.begin() + i + 1);
+        }
+    }
+
     // launch geometry + packed-weight offsets
     macs = 0; fused_params = d.reg_max;
     size_t woff = 0, boff = 0;
@@ -295,12 +321,21 @@ std::string Plan::build(const vti_desc& d) {
         if (op.kind != OP_CONV && op.kind != OP_CONV0) continue;
         const ConvRow& r = convs[op.conv];
         macs += r.macs(); fused_params += r.fused_params();
-        choose_conv_cfg(d.dtype, r, op.kind == OP_CONV0, d.max_batch, op.cfg);
+        if (op.fused >= 0) choose_conv_cfg(d.dtype, r, false, d.max_batch, op.cfg, 0, 0, 1, r.c2 / 16);   // whole Cout in one wave
+        else choose_conv_cfg(d.dtype, r, op.kind == OP_CONV0, d.max_batch, op.cfg);
         if (op.cfg.TH == 0) return "no launch configuration for conv " + r.name;
         op.cfg.wpk_off = woff;
         op.cfg.bias_off = boff;
         woff += packed_conv_bytes(r, op.kind == OP_CONV0, op.cfg);
         boff += (size_t)op.cfg.ntiles_n * 16;
+        if (op.fused >= 0) {
+            const ConvRow& r2 = convs[op.fused];
+            macs += r2.macs(); fused_params += r2.fused_params();
+            op.cfg.ntiles2 = (r2.c2 + 15) / 16; op.cfg.gemm_n2 = r2.c2;
+            op.cfg.wpk_off2 = woff; op.cfg.bias_off2 = boff;
+            woff += packed_stage2_bytes(d.dtype, r2, op.cfg.NREP);
+            boff += (size_t)op.cfg.ntiles2 * 16;
+        }
     }
     wpk_bytes = woff; bias_floats = boff;
     return "";

@@ -85,11 +85,16 @@ int32_t vti_conv_at(const vti_ctx* c, int32_t i, vti_conv_info* o) {
     o->c1 = r.c1; o->c2 = r.c2; o->k = r.k; o->s = r.s; o->kind = r.kind;
     o->h_in = r.h_in; o->w_in = r.w_in; o->h_out = r.h_out; o->w_out = r.w_out;
     o->macs = r.macs();
-    for (const Op& op : c->plan.ops)
-        if ((op.kind == OP_CONV || op.kind == OP_CONV0) && op.conv == i) {
+    for (const Op& op : c->plan.ops) {
+        if (op.kind != OP_CONV && op.kind != OP_CONV0) continue;
+        if (op.conv == i) {
             o->tile_h = op.cfg.TH; o->tile_w = op.cfg.TW; o->waves_n = op.cfg.WN; o->nrep = op.cfg.NREP;
             o->lds_bytes = (int32_t)op.cfg.lds;
+        } else if (op.fused == i) {     // runs inside its producer's kernel, on that kernel's geometry
+            o->tile_h = op.cfg.TH; o->tile_w = op.cfg.TW; o->waves_n = 1; o->nrep = op.cfg.ntiles2;
+            o->lds_bytes = 0; o->fused = 1;
         }
+    }
     return VTI_OK;
 }
 
@@ -245,6 +250,15 @@ int32_t vti_forward(vti_ctx* c, const uint8_t* input, int32_t B, int32_t swap_rb
                              op.has_res ? buf_ptr(c, op.res.buf, input, proto) : nullptr,
                              op.has_res ? P.bufs[op.res.buf].C : 0, op.res.coff,
                              (const char*)c->d_wpk + g.wpk_off, c->d_bias + g.bias_off, op.out_f32, swap_rb);
+            if (op.fused >= 0) {
+                const Buf& o2 = P.bufs[op.out2.buf];
+                p.w2 = (const char*)c->d_wpk + g.wpk_off2;
+                p.bias2 = c->d_bias + g.bias_off2;
+                p.out2 = buf_ptr(c, op.out2.buf, input, proto);
+                p.Cout2 = g.gemm_n2; p.ntiles2 = g.ntiles2; p.out2_ld = o2.C; p.out2_coff = op.out2.coff;
+                p.act2 = P.convs[op.fused].kind == 0; p.out2_f32 = op.out2_f32 ? 1 : 0;
+                p.scalar_store2 = (g.gemm_n2 % 4 || o2.C % 4 || op.out2.coff % 4) ? 1 : 0;
+            }
             const bool deconv = r.kind == 2;
             const int ks = deconv ? 1 : r.k, s = deconv ? 1 : r.s;
             VTI_HIP(c, launch_conv(dt, ks, s, g.NREP, op.kind == OP_CONV0 ? 1 : 0, p, g.lds, st), r.name.c_str());
@@ -378,6 +392,7 @@ int32_t vti_debug_conv_output(vti_ctx* c, int32_t i, int32_t B, float* out, void
     if (rc) return rc;
     if (i < 0 || i >= (int32_t)c->plan.convs.size() || !out) return fail(c, VTI_ERR_ARG, "vti_debug_conv_output: bad argument");
     const View& v = c->plan.conv_out[i];
+    if (v.buf < 0) return fail(c, VTI_ERR_UNSUPPORTED, "vti_debug_conv_output: this conv is fused into the next one; its output is never materialised");
     const Buf& b = c->plan.bufs[v.buf];
     const void* src = buf_ptr(c, v.buf, c->last_input, c->last_proto);
     if (!src) return fail(c, VTI_ERR_STATE, "vti_debug_conv_output: run vti_forward first");

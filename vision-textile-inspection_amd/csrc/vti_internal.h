@@ -49,6 +49,9 @@ struct ConvCfg {         // launch geometry chosen at plan time
     size_t lds = 0;
     size_t wpk_off = 0;  // byte offset of this conv's packed weights
     size_t bias_off = 0; // float offset of this conv's bias
+    // fused second stage (a 1x1 conv applied to this conv's register tile), 0 tiles = none
+    int ntiles2 = 0, gemm_n2 = 0;
+    size_t wpk_off2 = 0, bias_off2 = 0;
 };
 
 struct Op {
@@ -57,6 +60,9 @@ struct Op {
     View in, out, res;
     bool has_res = false;
     bool out_f32 = false;
+    int fused = -1;      // conv index of a 1x1 conv fused into this op's epilogue (its own op is dropped)
+    View out2;           // where the fused conv writes
+    bool out2_f32 = false;
     int lane = 0;        // stream the op is enqueued on (OP_FORK/OP_JOIN: the side lane that starts/finishes)
     ConvCfg cfg;
 };
@@ -91,12 +97,16 @@ struct ConvParams {
     int act, out_f32, deconv_c, swap_rb, nchunks, ntiles_n, has_res, scalar_store;
     unsigned pw_magic, rw_magic, tw_magic;   // ceil(2^32 / {PW, raw-row-bytes, TW}): division-free indexing
     unsigned wpk_bytes;                  // bytes of this conv's packed weights (buffer-load range check)
+    // fused 1x1 second stage: out2 = act2(W2 . silu(conv + bias) + bias2), never touching HBM in between
+    const void* w2; const float* bias2; void* out2;
+    int Cout2, ntiles2, out2_ld, out2_coff, act2, out2_f32, scalar_store2;
     unsigned long long* stamps;          // diagnostic build only (VTI_STAMPS): 16 s_memtime slots per workgroup
 };
 
 // dtype: VTI_F16/VTI_F32; mode 0 = NHWC conv, 1 = conv0 (u8 input, im2col K=27->32)
 hipError_t launch_conv(int dtype, int ks, int stride, int nrep, int mode, const ConvParams& p,
                        size_t lds_bytes, hipStream_t st);
+bool conv_fusable(int nrep, int nrep2);   // is there a (3x3 NREP) + (1x1 NREP2) fused instantiation
 size_t conv_lds_bytes(int ks, int stride, int mode, int TH, int TW, int WN, int NREP);
 bool conv_cfg_fits(int ks, int stride, int mode, int TH, int TW, int WN, int NREP);
 
@@ -142,6 +152,9 @@ void choose_conv_cfg(int dtype, const ConvRow& r, bool conv0, int max_batch, Con
 void pack_conv(int dtype, const ConvRow& r, bool conv0, const ConvCfg& c, const float* w, const float* b,
                uint8_t* dst_w, float* dst_b);
 size_t packed_conv_bytes(const ConvRow& r, bool conv0, const ConvCfg& c);
+// fused second stage: the 1x1 conv `r2` packed against the accumulator layout of a producer with nrep1 cout tiles
+void pack_conv_stage2(int dtype, const ConvRow& r2, int nrep1, const float* w, const float* b, uint8_t* dst_w, float* dst_b);
+size_t packed_stage2_bytes(int dtype, const ConvRow& r2, int nrep1);
 // weights.cpp: parse VTIW1 + pack into MFMA fragment order (host memory)
 std::string pack_weights(const Plan& plan, const void* blob, size_t nbytes,
                          std::vector<uint8_t>& wpk, std::vector<float>& bias);

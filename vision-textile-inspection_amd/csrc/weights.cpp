@@ -62,6 +62,33 @@ void pack_conv(int dtype, const ConvRow& r, bool conv0, const ConvCfg& c, const 
     for (int n = 0; n < c.ntiles_n * 16; ++n) bd[n] = n < c.gemm_n ? b[deconv ? n % r.c2 : n] : 0.f;
 }
 
+// Fused 1x1 stage.  The producer's accumulator lane (g = lane>>4) holds, for its cout tile n, channels
+// 16n + 4g + j (j<4).  fp16: one 32-deep MFMA step t consumes tiles 2t and 2t+1, so operand element jj of
+// lane group g is mid-channel 32t + 16(jj>>2) + 4g + (jj&3); the weights are packed with that same map.
+// fp32: one 16-deep step per tile with element i = channel 16t + 4g + i, i.e. the standard chunk packing.
+size_t packed_stage2_bytes(int dtype, const ConvRow& r2, int nrep1) {
+    const int kt = dtype == VTI_F16 ? (nrep1 + 1) / 2 : nrep1;
+    return (size_t)kt * ((r2.c2 + 15) / 16) * 1024;
+}
+
+void pack_conv_stage2(int dtype, const ConvRow& r2, int nrep1, const float* w, const float* b, uint8_t* dst, float* bd) {
+    const bool f16 = dtype == VTI_F16;
+    const int kt = f16 ? (nrep1 + 1) / 2 : nrep1, VEC = f16 ? 8 : 4;
+    const int nt2 = (r2.c2 + 15) / 16;
+    for (int t = 0; t < kt; ++t)
+        for (int n2 = 0; n2 < nt2; ++n2)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int jj = 0; jj < VEC; ++jj) {
+                    const int g = lane >> 4, co = n2 * 16 + (lane & 15);
+                    const int cm = f16 ? 32 * t + 16 * (jj >> 2) + 4 * g + (jj & 3) : 16 * t + 4 * g + jj;
+                    const float v = (co < r2.c2 && cm < r2.c1) ? w[(size_t)co * r2.c1 + cm] : 0.f;
+                    const size_t e = (((size_t)t * nt2 + n2) * 64 + lane) * VEC + jj;
+                    if (f16) ((_Float16*)dst)[e] = (_Float16)v;
+                    else ((float*)dst)[e] = v;
+                }
+    for (int n = 0; n < nt2 * 16; ++n) bd[n] = n < r2.c2 ? b[n] : 0.f;
+}
+
 std::string pack_weights(const Plan& plan, const void* blob, size_t nbytes, std::vector<uint8_t>& wpk,
                          std::vector<float>& bias) {
     const uint8_t* p = (const uint8_t*)blob;
@@ -77,10 +104,13 @@ std::string pack_weights(const Plan& plan, const void* blob, size_t nbytes, std:
     wpk.assign(plan.wpk_bytes, 0);
     bias.assign(plan.bias_floats, 0.f);
 
-    // conv index -> op (cfg)
-    std::vector<const Op*> op_of(plan.convs.size(), nullptr);
+    // conv index -> op (cfg); a conv fused into its producer's epilogue maps to that producer
+    std::vector<const Op*> op_of(plan.convs.size(), nullptr), host_of(plan.convs.size(), nullptr);
     for (const Op& op : plan.ops)
-        if (op.kind == OP_CONV || op.kind == OP_CONV0) op_of[op.conv] = &op;
+        if (op.kind == OP_CONV || op.kind == OP_CONV0) {
+            op_of[op.conv] = &op;
+            if (op.fused >= 0) host_of[op.fused] = &op;
+        }
 
     size_t off = sizeof(Hdr);
     for (size_t i = 0; i < plan.convs.size(); ++i) {
@@ -100,6 +130,11 @@ std::string pack_weights(const Plan& plan, const void* blob, size_t nbytes, std:
         memcpy(w.data(), p + off, 4 * nw); off += 4 * nw;
         memcpy(b.data(), p + off, 4 * (size_t)r.c2); off += 4 * (size_t)r.c2;
 
+        if (host_of[i]) {
+            const ConvCfg& hc = host_of[i]->cfg;
+            pack_conv_stage2(plan.desc.dtype, r, hc.NREP, w.data(), b.data(), wpk.data() + hc.wpk_off2, bias.data() + hc.bias_off2);
+            continue;
+        }
         const Op& op = *op_of[i];
         pack_conv(plan.desc.dtype, r, op.kind == OP_CONV0, op.cfg, w.data(), b.data(), wpk.data() + op.cfg.wpk_off,
                   bias.data() + op.cfg.bias_off);

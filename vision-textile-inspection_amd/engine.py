@@ -57,7 +57,8 @@ class Engine:
             check(self._ctx, lib().vti_conv_at(self._ctx, i, C.byref(info)))
             out.append(dict(name=info.name.decode(), c1=info.c1, c2=info.c2, k=info.k, s=info.s, kind=info.kind,
                             h_in=info.h_in, w_in=info.w_in, h_out=info.h_out, w_out=info.w_out, macs=info.macs,
-                            tile=(info.tile_h, info.tile_w), waves_n=info.waves_n, nrep=info.nrep, lds=info.lds_bytes))
+                            tile=(info.tile_h, info.tile_w), waves_n=info.waves_n, nrep=info.nrep, lds=info.lds_bytes,
+                            fused=bool(info.fused)))
         return out
 
     @property
