@@ -9,6 +9,8 @@
 // libraries they restate do not fuse multiply-adds in these formulas).
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <vector>
 
 #include "vti_internal.h"
 
@@ -96,21 +98,24 @@ hipError_t launch_letterbox(const uint8_t* frames, int B, int H0, int W0, uint8_
 // =====================================================================================
 constexpr int NMS_THREADS = 512;
 constexpr int NMS_LDS_BOX = 2048;         // sorted boxes/areas/keep list live in LDS up to this many candidates
-constexpr int NMS_LDS_KEYS = 8192;        // candidates sorted in LDS up to this many, else in global scratch
+constexpr int NMS_LDS_KEYS = 2048;        // == NMS_LDS_BOX: beyond this many candidates everything lives in global scratch
 constexpr float NMS_MAX_WH = 7680.0f;     // Ultralytics class offset
 
 static inline size_t nms_pow2(size_t n) { size_t p = 1; while (p < n) p <<= 1; return p; }
 static inline size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
 
-struct NmsWsLayout { size_t keys, boxes, area, cls, keep, per_frame; };
+struct NmsWsLayout { size_t keys, keys2, boxes, area, cls, keep, kid, kcls, per_frame; };
 static NmsWsLayout nms_layout(int A) {
     NmsWsLayout l;
     size_t off = 0;
     l.keys = off; off += align256(nms_pow2((size_t)A) * 8);
+    l.keys2 = off; off += align256(nms_pow2((size_t)A) * 8);
     l.boxes = off; off += align256((size_t)A * 16);
     l.area = off; off += align256((size_t)A * 4);
     l.cls = off; off += align256((size_t)A * 4);
     l.keep = off; off += align256((size_t)A * 4);
+    l.kid = off; off += align256((size_t)A * 4);
+    l.kcls = off; off += align256((size_t)A * 4);
     l.per_frame = off;
     return l;
 }
@@ -140,43 +145,36 @@ __global__ __launch_bounds__(256) void nms_scan_kernel(const float* __restrict__
     }
 }
 
+#ifdef VTI_STAMPS   // diagnostic build only: per-frame phase stamps of nms_kernel
+__device__ unsigned long long g_nms_stamps[4096 * 8];
+#define NMS_STAMP(i)                                                                                   \
+    do {                                                                                               \
+        if (tid == 0 && b < 4096) {                                                                    \
+            unsigned long long t_;                                                                     \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                 \
+            g_nms_stamps[b * 8 + (i)] = t_;                                                            \
+        }                                                                                              \
+    } while (0)
+#else
+#define NMS_STAMP(i) do { } while (0)
+#endif
+
 // Stage 2: one workgroup per frame -- sort, greedy suppression, output rows.
-__global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const float* __restrict__ pred, int A, int nc, int nm,
-                                                          float conf, double iou, int max_det, int agnostic,
-                                                          float* __restrict__ dets, int* __restrict__ counts,
-                                                          char* ws, NmsWsLayout L, const int* __restrict__ ncand) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    unsigned long long* lds_keys = (unsigned long long*)smem;             // NMS_LDS_KEYS entries
-    f32x4* lds_boxes = (f32x4*)(smem + NMS_LDS_KEYS * 8);                 // NMS_LDS_BOX entries
-    float* lds_area = (float*)(lds_boxes + NMS_LDS_BOX);
-    int* lds_keep = (int*)(lds_area + NMS_LDS_BOX);
-    unsigned char* suppressed = (unsigned char*)(lds_keep + NMS_LDS_BOX);  // A bytes
-
-    const int b = blockIdx.x, tid = threadIdx.x;
-    const int no = 4 + nc + nm;
-    const float* P = pred + (size_t)b * no * A;
-    char* wsb = ws + (size_t)b * L.per_frame;
-    unsigned long long* g_keys = (unsigned long long*)(wsb + L.keys);
-    int* cls_of = (int*)(wsb + L.cls);
-    const int n = ncand[b];
-    // flat pointers: LDS for the common case, global scratch for pathological candidate counts
-    f32x4* boxes = n <= NMS_LDS_BOX ? lds_boxes : (f32x4*)(wsb + L.boxes);
-    float* area = n <= NMS_LDS_BOX ? lds_area : (float*)(wsb + L.area);
-    int* keep = n <= NMS_LDS_BOX ? lds_keep : (int*)(wsb + L.keep);
-    if (n == 0) {
-        if (tid == 0) counts[b] = 0;
-        for (int i = tid; i < max_det * (6 + nm); i += NMS_THREADS) dets[(size_t)b * max_det * (6 + nm) + i] = 0.f;
-        return;
-    }
-
-    // 2. bitonic sort of the keys (LDS when they fit, global scratch otherwise)
+// The body is instantiated per storage case (keys / boxes in LDS or in global scratch) and force-inlined
+// at call sites where each pointer has ONE origin, so the compiler emits ds_* / global_* instructions
+// instead of flat_* ones (a pointer chosen by `cond ? lds : global` is a flat pointer: every access then
+// waits on both memory counters and costs several hundred cycles).
+template <typename KeyP, typename BoxP, typename FltP, typename IntP>
+__device__ __forceinline__ void nms_body(const float* __restrict__ P, int A, int nc, int nm, int n, double iou, int max_det,
+                                         int agnostic, float* __restrict__ D, int* __restrict__ counts, int b,
+                                         const unsigned long long* __restrict__ g_keys_in, KeyP keys, BoxP boxes, FltP area,
+                                         IntP keep, IntP kid, IntP kcls, unsigned char* suppressed,
+                                         const int* __restrict__ cls_of) {
+    const int tid = threadIdx.x;
+    // 2. bitonic sort of the keys
     int Pn = 1;
     while (Pn < n) Pn <<= 1;
-    unsigned long long* keys = (Pn <= NMS_LDS_KEYS) ? lds_keys : g_keys;
-    for (int i = tid; i < Pn; i += NMS_THREADS) {
-        const unsigned long long k = i < n ? g_keys[i] : ~0ull;
-        if (keys != g_keys || i >= n) keys[i] = k;
-    }
+    for (int i = tid; i < Pn; i += NMS_THREADS) keys[i] = i < n ? g_keys_in[i] : ~0ull;
     __syncthreads();
     for (int k = 2; k <= Pn; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
@@ -191,7 +189,7 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const float* __restric
             __syncthreads();
         }
     }
-
+    NMS_STAMP(1);
     // 3. boxes in sorted order: xywh -> xyxy, + class offset, areas (all fp32 as torch computes them)
     for (int i = tid; i < n; i += NMS_THREADS) {
         const int a = (int)(keys[i] & 0xffffffffu);
@@ -205,56 +203,157 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const float* __restric
         suppressed[i] = 0;
     }
     __syncthreads();
-
-    // 4. greedy suppression in score order; stops once max_det boxes are kept
+    NMS_STAMP(2);
+    // 4. greedy suppression in score order, 64 candidates per round (same decisions as the sequential
+    // loop, 3 barriers per 64 candidates instead of one per kept box):
+    //   A. all threads: bit (i, j) of the 64x64 intra-block matrix = "i suppresses j" (j > i)
+    //   B. wave 0: walk the block's still-alive candidates in order with 64-bit masks
+    //   C. all threads: the block's kept boxes suppress every later candidate
+    __shared__ unsigned long long s_rows[64], s_keptmask;
+    __shared__ int s_kept;
+    auto iou_gt = [&](const f32x4& bi, float ai, const f32x4& bj, float aj) -> bool {
+        const float xx1 = fmaxf(bi[0], bj[0]), yy1 = fmaxf(bi[1], bj[1]);
+        const float xx2 = fminf(bi[2], bj[2]), yy2 = fminf(bi[3], bj[3]);
+        const float w = fmaxf(0.0f, xx2 - xx1), h = fmaxf(0.0f, yy2 - yy1);
+        const float inter = w * h;
+        const float ovr = inter / (ai + aj - inter);
+        return (double)ovr > iou;
+    };
     int kept = 0;
-    for (int i = 0; i < n; ++i) {
-        if (suppressed[i]) continue;       // uniform: LDS state is stable between barriers
-        if (tid == 0) keep[kept] = i;
-        ++kept;
-        if (kept == max_det) break;
-        const f32x4 bi = boxes[i];
-        const float ai = area[i];
-        for (int j = i + 1 + tid; j < n; j += NMS_THREADS) {
-            if (suppressed[j]) continue;
-            const f32x4 bj = boxes[j];
-            const float xx1 = fmaxf(bi[0], bj[0]), yy1 = fmaxf(bi[1], bj[1]);
-            const float xx2 = fminf(bi[2], bj[2]), yy2 = fminf(bi[3], bj[3]);
-            const float w = fmaxf(0.0f, xx2 - xx1), h = fmaxf(0.0f, yy2 - yy1);
-            const float inter = w * h;
-            const float ovr = inter / (ai + area[j] - inter);
-            if ((double)ovr > iou) suppressed[j] = 1;
+    if (tid == 0) s_kept = 0;
+    for (int base = 0; base < n && kept < max_det; base += 64) {
+        const int cnt = min(64, n - base);
+        if (tid < 64) s_rows[tid] = 0;
+        __syncthreads();
+        // A: thread -> (row i, 8 columns)
+        for (int e = tid; e < 64 * 8; e += NMS_THREADS) {
+            const int i = e >> 3, jg = (e & 7) * 8;
+            if (i >= cnt || jg + 7 <= i) continue;
+            const f32x4 bi = boxes[base + i];
+            const float ai = area[base + i];
+            unsigned long long m = 0;
+            for (int k = 0; k < 8; ++k) {
+                const int j = jg + k;
+                if (j > i && j < cnt && iou_gt(bi, ai, boxes[base + j], area[base + j])) m |= 1ull << j;
+            }
+            if (m) atomicOr(&s_rows[i], m);
+        }
+        __syncthreads();
+        // B: wave 0, lane l <-> candidate base+l
+        if (tid < 64) {
+            const bool alive_l = tid < cnt && !suppressed[base + tid];
+            unsigned long long alive = __ballot(alive_l);
+            unsigned long long keptmask = 0;
+            int k_ = kept;
+            while (alive && k_ < max_det) {
+                const int i = __ffsll((long long)alive) - 1;
+                keptmask |= 1ull << i;
+                if (tid == 0) keep[k_] = base + i;
+                ++k_;
+                alive &= ~(s_rows[i] | (1ull << i));
+            }
+            if (tid == 0) { s_keptmask = keptmask; s_kept = k_; }
+        }
+        __syncthreads();
+        kept = s_kept;
+        // C: later candidates vs this block's kept boxes
+        const unsigned long long km = s_keptmask;
+        if (kept < max_det) {
+            for (int j = base + 64 + tid; j < n; j += NMS_THREADS) {
+                if (suppressed[j]) continue;
+                const f32x4 bj = boxes[j];
+                const float aj = area[j];
+                unsigned long long r = km;
+                while (r) {
+                    const int i = __ffsll((long long)r) - 1;
+                    r &= r - 1;
+                    if (iou_gt(boxes[base + i], area[base + i], bj, aj)) { suppressed[j] = 1; break; }
+                }
+            }
         }
         __syncthreads();
     }
-    __syncthreads();
-
-    // 5. output rows [x1,y1,x2,y2,conf,cls,coeffs], zero the unused tail
-    const int row = 6 + nm;
-    float* D = dets + (size_t)b * max_det * row;
-    for (int e = tid; e < max_det * row; e += NMS_THREADS) {
-        const int k = e / row, f = e - k * row;
-        float v = 0.f;
-        if (k < kept) {
-            const int a = (int)(keys[keep[k]] & 0xffffffffu);
-            const int j = cls_of[a];
-            if (f < 4) {
-                const float cx = P[a], cy = P[(size_t)A + a], w = P[(size_t)2 * A + a], h = P[(size_t)3 * A + a];
-                const float dw = w / 2.0f, dh = h / 2.0f;
-                v = f == 0 ? cx - dw : f == 1 ? cy - dh : f == 2 ? cx + dw : cy + dh;
-            } else if (f == 4) v = P[(size_t)(4 + j) * A + a];
-            else if (f == 5) v = (float)j;
-            else v = P[(size_t)(4 + nc + (f - 6)) * A + a];
-        }
-        D[e] = v;
+    NMS_STAMP(3);
+    // 5. output rows [x1,y1,x2,y2,conf,cls,coeffs], zero the unused tail.  Anchor id and class of every
+    // kept row are gathered once, then each wave streams whole rows (no per-element division, one level of
+    // dependent global loads).
+    for (int k = tid; k < kept; k += NMS_THREADS) {
+        const int a = (int)(keys[keep[k]] & 0xffffffffu);
+        kid[k] = a;
+        kcls[k] = cls_of[a];
     }
+    __syncthreads();
+    const int row = 6 + nm;
+    const unsigned row_magic = (unsigned)((0x100000000ull + (unsigned)row - 1) / (unsigned)row);
+    auto elem = [&](int e) -> float {          // element e of the kept rows: (k, f) = (e / row, e % row)
+        const int k = (int)__umulhi((unsigned)e, row_magic), f = e - k * row;
+        const int a = kid[k], j = kcls[k];
+        if (f < 4) {
+            const float c_ = P[(size_t)(f & 1) * A + a], s_ = P[(size_t)(2 + (f & 1)) * A + a];   // centre, size of this axis
+            const float d_ = s_ / 2.0f;
+            return f < 2 ? c_ - d_ : c_ + d_;
+        }
+        if (f == 4) return P[(size_t)(4 + j) * A + a];
+        if (f == 5) return (float)j;
+        return P[(size_t)(4 + nc + (f - 6)) * A + a];
+    };
+    const int nel = kept * row, ntot = max_det * row;
+    for (int e0 = tid; e0 < nel; e0 += 4 * NMS_THREADS) {      // 4 independent gathers in flight per thread
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = e0 + u * NMS_THREADS < nel ? elem(e0 + u * NMS_THREADS) : 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (e0 + u * NMS_THREADS < nel) D[e0 + u * NMS_THREADS] = v[u];
+    }
+    for (int e = nel + tid; e < ntot; e += NMS_THREADS) D[e] = 0.f;
+    __syncthreads();
+    NMS_STAMP(4);
     if (tid == 0) counts[b] = kept;
+}
+
+__global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const float* __restrict__ pred, int A, int nc, int nm,
+                                                          float conf, double iou, int max_det, int agnostic,
+                                                          float* __restrict__ dets, int* __restrict__ counts,
+                                                          char* ws, NmsWsLayout L, const int* __restrict__ ncand) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned long long* lds_keys = (unsigned long long*)smem;             // NMS_LDS_KEYS entries
+    f32x4* lds_boxes = (f32x4*)(smem + NMS_LDS_KEYS * 8);                 // NMS_LDS_BOX entries
+    float* lds_area = (float*)(lds_boxes + NMS_LDS_BOX);
+    int* lds_keep = (int*)(lds_area + NMS_LDS_BOX);                       // keep | kept anchor ids | kept classes
+    unsigned char* suppressed = (unsigned char*)(lds_keep + 3 * NMS_LDS_BOX);  // A bytes
+
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int no = 4 + nc + nm;
+    const float* P = pred + (size_t)b * no * A;
+    char* wsb = ws + (size_t)b * L.per_frame;
+    unsigned long long* g_keys = (unsigned long long*)(wsb + L.keys);
+    const int* cls_of = (const int*)(wsb + L.cls);
+    float* D = dets + (size_t)b * max_det * (6 + nm);
+    const int n = ncand[b];
+    if (n == 0) {
+        if (tid == 0) counts[b] = 0;
+        for (int i = tid; i < max_det * (6 + nm); i += NMS_THREADS) D[i] = 0.f;
+        return;
+    }
+    NMS_STAMP(0);
+    if (n <= NMS_LDS_BOX && max_det <= NMS_LDS_BOX) {
+        nms_body(P, A, nc, nm, n, iou, max_det, agnostic, D, counts, b, g_keys, lds_keys, lds_boxes, lds_area, lds_keep,
+                 lds_keep + NMS_LDS_BOX, lds_keep + 2 * NMS_LDS_BOX, suppressed, cls_of);
+    } else {
+        // pathological candidate counts: everything but the suppressed flags in global scratch.  The keys are
+        // sorted in a second scratch array so the unsorted input is not aliased.
+        int* g_int = (int*)(wsb + L.keep);          // A ints: keep list; kept ids/classes reuse boxes' tail? no: own arrays below
+        nms_body(P, A, nc, nm, n, iou, max_det, agnostic, D, counts, b, g_keys, (unsigned long long*)(wsb + L.keys2),
+                 (f32x4*)(wsb + L.boxes), (float*)(wsb + L.area), g_int, (int*)(wsb + L.kid), (int*)(wsb + L.kcls), suppressed,
+                 cls_of);
+    }
 }
 
 hipError_t launch_nms(const float* pred, int B, int A, int nc, int nm, float conf, double iou, int max_det,
                       int agnostic, float* dets, int* counts, void* ws, hipStream_t st) {
     if (B == 0) return hipSuccess;
-    const size_t lds = (size_t)NMS_LDS_KEYS * 8 + (size_t)NMS_LDS_BOX * 24 + (((size_t)A + 15) & ~(size_t)15);
+    const size_t lds = (size_t)NMS_LDS_KEYS * 8 + (size_t)NMS_LDS_BOX * 32 + (((size_t)A + 15) & ~(size_t)15);
     if (lds > 150 * 1024) return hipErrorInvalidValue;   // > ~39k anchors: unsupported
     static bool attr_set = false;
     if (!attr_set) {
@@ -269,6 +368,30 @@ hipError_t launch_nms(const float* pred, int B, int A, int nc, int nm, float con
     hipLaunchKernelGGL(nms_scan_kernel, dim3((A + 255) / 256, B), dim3(256), 0, st, pred, A, nc, nm, conf, (char*)ws, L, ncand);
     hipLaunchKernelGGL(nms_kernel, dim3(B), dim3(NMS_THREADS), lds, st, pred, A, nc, nm, conf, iou, max_det, agnostic,
                        dets, counts, (char*)ws, L, ncand);
+#ifdef VTI_STAMPS
+    {
+        (void)hipStreamSynchronize(st);
+        static int calls = 0;
+        if (++calls == 3) {
+            std::vector<unsigned long long> h(4096 * 8);
+            std::vector<int> hc(B), hn(B);
+            (void)hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_nms_stamps), h.size() * 8);
+            (void)hipMemcpy(hc.data(), counts, B * 4, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(hn.data(), ncand, B * 4, hipMemcpyDeviceToHost);
+            const char* nm_[4] = {"sort", "boxes", "greedy", "output"};
+            int worst = 0;
+            for (int b = 1; b < B; ++b) if (h[b * 8 + 4] - h[b * 8] > h[worst * 8 + 4] - h[worst * 8]) worst = b;
+            fprintf(stderr, "[nms stamps] slowest frame %d: candidates %d kept %d\n", worst, hn[worst], hc[worst]);
+            for (int i = 0; i < 4; ++i) {
+                std::vector<long long> d;
+                for (int b = 0; b < B; ++b) if (hn[b] > 0) d.push_back((long long)(h[b * 8 + i + 1] - h[b * 8 + i]));
+                std::sort(d.begin(), d.end());
+                fprintf(stderr, "[nms stamps] %-7s median %8lld  max %8lld  slowest-frame %8lld cycles\n", nm_[i],
+                        d.empty() ? 0 : d[d.size() / 2], d.empty() ? 0 : d.back(), (long long)(h[worst * 8 + i + 1] - h[worst * 8 + i]));
+            }
+        }
+    }
+#endif
     return hipGetLastError();
 }
 
@@ -366,7 +489,7 @@ __global__ __launch_bounds__(256) void masks_kernel(const float* __restrict__ de
                         for (int k = 0; k < nm; k += PV) {
                             const pvec v = *(const pvec*)(pp + k);
 #pragma unroll
-                            for (int j = 0; j < PV; ++j) acc += coef[k + j] * (float)v[j];
+                            for (int j = 0; j < PV; ++j) acc = __builtin_fmaf(coef[k + j], (float)v[j], acc);   // summation order is free here
                         }
                     } else {
                         for (int k = 0; k < nm; ++k) acc += coef[k] * (float)pp[k];
