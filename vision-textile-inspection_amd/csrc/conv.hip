@@ -84,64 +84,90 @@ size_t conv_lds_bytes(int ks, int stride, int mode, int TH, int TW, int WN, int 
     return 4 * plane + (size_t)WN * NREP * taps * 1024 + raw;
 }
 
-// ---- shared epilogue: bias, SiLU, residual, store 4 consecutive channels per lane.
+// ---- shared epilogue: bias, SiLU, residual, stores.
+// With the row permutation of weights.cpp, accumulator lane-group g = lane>>4 of a wave holds, over its
+// NREP n-tiles, the 4*NREP CONSECUTIVE output channels crun .. crun+4*NREP-1 of its pixel
+// (tile n, element j <-> channel crun + 4n + j).  fp16 outputs therefore go out as 16-byte stores (two tiles
+// at a time) that tile whole 128-byte lines; residuals are read the same way.
 template <typename T, int NREP>
 __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc)[MREP][NREP], const bool (&pvalid)[MREP],
                                               const int (&opy)[MREP], const int (&opx)[MREP], int b, int nt0, int wn,
                                               int lane) {
-    // Bias (and the residual of a whole pixel row) are loaded up front: a load inside the store loop
-    // would make every block wait on vmcnt(0), i.e. on all earlier STORES as well.
+    // Bias (and the residual of a whole pixel) are loaded up front: a load inside the store loop would make
+    // every block wait on vmcnt(0), i.e. on all earlier STORES as well.
     constexpr bool FAST = sizeof(T) == 2;
+    const int crun = (nt0 + wn * NREP) * 16 + (lane >> 4) * 4 * NREP;
     f32x4 bias_r[NREP];
-    int cout_r[NREP];
 #pragma unroll
     for (int n = 0; n < NREP; ++n) {
-        cout_r[n] = (nt0 + wn * NREP + n) * 16 + (lane >> 4) * 4;
-        const int cb = cout_r[n] < p.ntiles_n * 16 ? cout_r[n] : 0;     // bias is padded to 16 floats per n-tile
+        const int cb = crun + 4 * n < p.ntiles_n * 16 ? crun + 4 * n : 0;     // bias is padded to whole groups
         bias_r[n] = *(const f32x4*)(p.bias + cb);
     }
     if (!p.scalar_store && !p.out_f32 && !p.deconv_c) {
-        // common case: T output, vector stores, plain NHWC addressing -- no per-element branches
+        // common case: T output, vector stores, plain NHWC addressing
         const bool has_res = __builtin_amdgcn_readfirstlane(p.has_res) != 0;
 #pragma unroll
         for (int m = 0; m < MREP; ++m) {
             if (!pvalid[m]) continue;
             const size_t opix = ((size_t)(b * p.Hout + opy[m])) * p.Wout + opx[m];
-            T* op = (T*)p.out + opix * p.out_ld + p.out_coff;
+            T* op = (T*)p.out + opix * p.out_ld + p.out_coff + crun;
             f32x4 res_r[NREP];
             if (has_res) {
-                const T* rp = (const T*)p.res + opix * p.res_ld + p.res_coff;
+                const T* rp = (const T*)p.res + opix * p.res_ld + p.res_coff + crun;
 #pragma unroll
                 for (int n = 0; n < NREP; ++n) {
                     res_r[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    if (cout_r[n] < p.Cout) {
+                    if (crun + 4 * n < p.Cout) {
                         if constexpr (sizeof(T) == 2) {
-                            const half4 r = *(const half4*)(rp + cout_r[n]);
+                            const half4 r = *(const half4*)(rp + 4 * n);
 #pragma unroll
                             for (int j = 0; j < 4; ++j) res_r[n][j] = (float)r[j];
                         } else {
-                            res_r[n] = *(const f32x4*)(rp + cout_r[n]);
+                            res_r[n] = *(const f32x4*)(rp + 4 * n);
                         }
                     }
                 }
             }
+            f32x4 v[NREP];
 #pragma unroll
             for (int n = 0; n < NREP; ++n) {
-                if (cout_r[n] >= p.Cout) continue;
-                f32x4 v = acc[m][n] + bias_r[n];
+                v[n] = acc[m][n] + bias_r[n];
                 if (p.act) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = silu<FAST>(v[j]);
+                    for (int j = 0; j < 4; ++j) v[n][j] = silu<FAST>(v[n][j]);
                 }
-                if (has_res) v += res_r[n];
-                if constexpr (sizeof(T) == 2) {
-                    half4 hv;
+                if (has_res) v[n] += res_r[n];
+            }
+            if constexpr (sizeof(T) == 2) {
+                if constexpr (NREP % 2 == 0) {     // runs start 16-B aligned: one 16-byte store per tile pair
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) hv[j] = (half_t)v[j];
-                    *(half4*)(op + cout_r[n]) = hv;
+                    for (int n = 0; n < NREP; n += 2) {
+                        if (crun + 4 * n + 8 <= p.Cout) {
+                            half8 hv;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) { hv[j] = (half_t)v[n][j]; hv[4 + j] = (half_t)v[n + 1][j]; }
+                            *(half8*)(op + 4 * n) = hv;
+                        } else if (crun + 4 * n + 4 <= p.Cout) {
+                            half4 hv;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) hv[j] = (half_t)v[n][j];
+                            *(half4*)(op + 4 * n) = hv;
+                        }
+                    }
                 } else {
-                    *(f32x4*)(op + cout_r[n]) = v;
+#pragma unroll
+                    for (int n = 0; n < NREP; ++n) {
+                        if (crun + 4 * n >= p.Cout) continue;
+                        half4 hv;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) hv[j] = (half_t)v[n][j];
+                        *(half4*)(op + 4 * n) = hv;
+                    }
                 }
+            } else {
+#pragma unroll
+                for (int n = 0; n < NREP; ++n)
+                    if (crun + 4 * n < p.Cout) *(f32x4*)(op + 4 * n) = v[n];
             }
         }
         return;
@@ -152,7 +178,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc)[
         if (!pvalid[m]) continue;
 #pragma unroll
         for (int n = 0; n < NREP; ++n) {
-            const int cout0 = cout_r[n];
+            const int cout0 = crun + 4 * n;
             if (cout0 >= p.Cout) continue;
             f32x4 v = acc[m][n] + bias_r[n];
             if (p.act) {
@@ -198,7 +224,6 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc)[
         }
     }
 }
-
 
 // Register-staged operand prefetch: a thread owns up to AR input-patch pieces and BR weight pieces
 // (16 B each) of a chunk.  issue() only starts the loads; commit() writes them to LDS.  The next chunk is
@@ -361,7 +386,7 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvParams p) {
             (void*)p.w2, 0, (int)(KT * p.ntiles2 * 1024), 0x00020000);
         f32x4 bias1[NREP];
 #pragma unroll
-        for (int n = 0; n < NREP; ++n) bias1[n] = *(const f32x4*)(p.bias + n * 16 + (lane >> 4) * 4);
+        for (int n = 0; n < NREP; ++n) bias1[n] = *(const f32x4*)(p.bias + (lane >> 4) * 4 * NREP + 4 * n);
         f32x4 acc2[MREP][NREP2];
 #pragma unroll
         for (int m = 0; m < MREP; ++m)
@@ -404,15 +429,16 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvParams p) {
         }
         // second-stage epilogue: bias2 (+SiLU for proto.cv3), T or fp32 output
         f32x4 bias2[NREP2];
+        const int crun2 = (lane >> 4) * 4 * NREP2;      // this lane's consecutive output-channel run
 #pragma unroll
-        for (int n = 0; n < NREP2; ++n) bias2[n] = *(const f32x4*)(p.bias2 + n * 16 + (lane >> 4) * 4);
+        for (int n = 0; n < NREP2; ++n) bias2[n] = *(const f32x4*)(p.bias2 + crun2 + 4 * n);
 #pragma unroll
         for (int m = 0; m < MREP; ++m) {
             if (!pvalid[m]) continue;
             const size_t o0 = (((size_t)(b * p.Hout + opy[m])) * p.Wout + opx[m]) * p.out2_ld + p.out2_coff;
 #pragma unroll
             for (int n = 0; n < NREP2; ++n) {
-                const int cout0 = n * 16 + (lane >> 4) * 4;
+                const int cout0 = crun2 + 4 * n;
                 if (cout0 >= p.Cout2) continue;
                 f32x4 v = acc2[m][n] + bias2[n];
                 if (p.act2) {

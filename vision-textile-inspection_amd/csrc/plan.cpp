@@ -101,7 +101,7 @@ void choose_conv_cfg(int dtype, const ConvRow& r, bool conv0, int max_batch, Con
     const int KC = f16 ? 32 : 16;
     const bool deconv = r.kind == 2;
     c.gemm_n = deconv ? 4 * r.c2 : r.c2;
-    c.ntiles_n = (c.gemm_n + 15) / 16;
+    c.ntiles_n = (c.gemm_n + 15) / 16;      // rounded up to whole NREP groups once NREP is chosen (below)
     c.nchunks = conv0 ? (32 / KC) : (r.c1 + KC - 1) / KC;
     const int ks = deconv ? 1 : r.k, st = deconv ? 1 : r.s;
     const int Ho = deconv ? r.h_in : r.h_out, Wo = deconv ? r.w_in : r.w_out;
@@ -112,6 +112,7 @@ void choose_conv_cfg(int dtype, const ConvRow& r, bool conv0, int max_batch, Con
         if (fwn && WN != fwn) continue;
         for (int NREP = 1; NREP <= 5; ++NREP) {
             if (fnrep && NREP != fnrep) continue;
+            if (deconv && r.c2 % (16 * NREP)) continue;  // a lane's channel run must stay inside one (dy,dx) plane
             const int BN = WN * NREP;                    // n-tiles per workgroup
             const int gy = (c.ntiles_n + BN - 1) / BN;
             const double n_eff = (double)c.ntiles_n / (gy * BN);
@@ -147,6 +148,7 @@ void choose_conv_cfg(int dtype, const ConvRow& r, bool conv0, int max_batch, Con
             }
         }
     }
+    if (c.TH) c.ntiles_n = (c.ntiles_n + c.NREP - 1) / c.NREP * c.NREP;   // whole channel groups (row permutation)
 }
 
 std::string Plan::build(const vti_desc& d) {

@@ -6,9 +6,16 @@
 //
 // Packed layout per conv (consumed by conv.hip):
 //   wpk[chunk][ntile][tap][lane 0..63][VEC]   VEC = 8 fp16 / 4 fp32 (16 B per lane)
-//   element = W[cout = ntile*16 + (lane&15)][cin = chunk*KC + (lane>>4)*VEC + j][tap]
+//   element = W[cout = perm(ntile, lane&15)][cin = chunk*KC + (lane>>4)*VEC + j][tap]
 // i.e. one (chunk, ntile, tap) fragment is the 1 KiB a wave loads as the MFMA "A" operand
 // (rows = output channels), zero padded past Cout / Cin.
+// Row permutation: a wave owns NREP consecutive n-tiles (a "group" of 16*NREP channels).  Row r of tile n
+// carries channel group*16*NREP + (r>>2)*4*NREP + n*4 + (r&3), so that accumulator lane-group g = r>>2 ends
+// up with the 4*NREP CONSECUTIVE channels [g*4*NREP, (g+1)*4*NREP) of its pixel: the epilogue then stores
+// (and reads residuals) in 16-byte pieces that tile whole 128-byte lines instead of scattered 8-byte ones.
+static inline int perm_cout(int nt, int r, int nrep) {
+    return (nt / nrep) * 16 * nrep + (r >> 2) * 4 * nrep + (nt % nrep) * 4 + (r & 3);
+}
 #include <cstring>
 
 #include "vti_internal.h"
@@ -37,7 +44,7 @@ void pack_conv(int dtype, const ConvRow& r, bool conv0, const ConvCfg& c, const 
             for (int tap = 0; tap < taps; ++tap)
                 for (int lane = 0; lane < 64; ++lane)
                     for (int j = 0; j < VEC; ++j) {
-                        const int ng = nt * 16 + (lane & 15);
+                        const int ng = perm_cout(nt, lane & 15, c.NREP);
                         const int kk = ck * KC + (lane >> 4) * VEC + j;
                         float v = 0.f;
                         if (ng < c.gemm_n) {
@@ -71,6 +78,11 @@ size_t packed_stage2_bytes(int dtype, const ConvRow& r2, int nrep1) {
     return (size_t)kt * ((r2.c2 + 15) / 16) * 1024;
 }
 
+// The producer's accumulator lane (g = lane>>4) holds for its cout tile n the mid channels
+// g*4*nrep1 + n*4 + j (the row permutation above).  fp16: one 32-deep MFMA step t consumes tiles 2t, 2t+1,
+// so operand element jj of lane group g is mid channel g*4*nrep1 + (2t + (jj>>2))*4 + (jj&3);
+// fp32: one 16-deep step per tile, element jj = g*4*nrep1 + t*4 + jj.  Output rows use the same
+// permutation with nrep2 = ceil(c2/16) (one group).
 void pack_conv_stage2(int dtype, const ConvRow& r2, int nrep1, const float* w, const float* b, uint8_t* dst, float* bd) {
     const bool f16 = dtype == VTI_F16;
     const int kt = f16 ? (nrep1 + 1) / 2 : nrep1, VEC = f16 ? 8 : 4;
@@ -79,9 +91,10 @@ void pack_conv_stage2(int dtype, const ConvRow& r2, int nrep1, const float* w, c
         for (int n2 = 0; n2 < nt2; ++n2)
             for (int lane = 0; lane < 64; ++lane)
                 for (int jj = 0; jj < VEC; ++jj) {
-                    const int g = lane >> 4, co = n2 * 16 + (lane & 15);
-                    const int cm = f16 ? 32 * t + 16 * (jj >> 2) + 4 * g + (jj & 3) : 16 * t + 4 * g + jj;
-                    const float v = (co < r2.c2 && cm < r2.c1) ? w[(size_t)co * r2.c1 + cm] : 0.f;
+                    const int g = lane >> 4, co = perm_cout(n2, lane & 15, nt2);
+                    const int n1 = f16 ? 2 * t + (jj >> 2) : t;
+                    const int cm = g * 4 * nrep1 + n1 * 4 + (f16 ? (jj & 3) : jj);
+                    const float v = (n1 < nrep1 && co < r2.c2 && cm < r2.c1) ? w[(size_t)co * r2.c1 + cm] : 0.f;
                     const size_t e = (((size_t)t * nt2 + n2) * 64 + lane) * VEC + jj;
                     if (f16) ((_Float16*)dst)[e] = (_Float16)v;
                     else ((float*)dst)[e] = v;
