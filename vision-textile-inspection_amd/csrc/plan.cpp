@@ -230,10 +230,10 @@ std::string Plan::build(const vti_desc& d) {
     const int feat[3] = {P3, P4, P5};
     const int strides[3] = {8, 16, 32};
     num_anchors = 0;
-    const int head_lane[3] = {2, 3, 0};
+    // lanes: level 0 is one lane (its kernels fill the chip); the small level-1/2 towers get a lane each
+    const int tower_lane[3][3] = {{2, 2, 2}, {3, 4, 5}, {6, 7, 0}};
     for (int l = 0; l < 3; ++l) {
         b.cur = &g_head[l];
-        b.lane = head_lane[l];
         const Buf fb = bufs[feat[l]];
         Level lv; lv.C = fb.C; lv.H = fb.H; lv.W = fb.W; lv.stride = strides[l];
         const char* towers[3] = {"cv2", "cv3", "cv4"};
@@ -241,6 +241,7 @@ std::string Plan::build(const vti_desc& d) {
         const int cout[3] = {4 * d.reg_max, d.nc, d.nm};
         int outs[3];
         for (int t = 0; t < 3; ++t) {
+            b.lane = tower_lane[l][t];
             const int t1 = b.new_buf(cmid[t], fb.H, fb.W), t2 = b.new_buf(cmid[t], fb.H, fb.W);
             outs[t] = b.new_buf(cout[t], fb.H, fb.W, EL_F32);
             char nm[64];
@@ -273,11 +274,12 @@ std::string Plan::build(const vti_desc& d) {
         sync(OP_FORK, 1); sync(OP_FORK, 2);
         add(g_proto); add(g_head[0]);
         add(g_p4);
-        sync(OP_FORK, 3);
+        sync(OP_FORK, 3); sync(OP_FORK, 4); sync(OP_FORK, 5);
         add(g_head[1]);
         add(g_p5);
+        sync(OP_FORK, 6); sync(OP_FORK, 7);
         add(g_head[2]);
-        sync(OP_JOIN, 1); sync(OP_JOIN, 2); sync(OP_JOIN, 3);
+        for (int l = 1; l <= 7; ++l) sync(OP_JOIN, l);
         Op op; op.kind = OP_DECODE; ops.push_back(op);
     }
 

@@ -131,7 +131,16 @@ __global__ __launch_bounds__(256) void nms_scan_kernel(const float* __restrict__
     const float* P = pred + (size_t)b * (4 + nc + nm) * A;
     float best = P[(size_t)4 * A + a];
     int j = 0;
-    for (int c = 1; c < nc; ++c) {
+    int c = 1;
+    for (; c + 8 <= nc; c += 8) {            // 8 independent loads in flight, then the ordered compares
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = P[(size_t)(4 + c + u) * A + a];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (v[u] > best) { best = v[u]; j = c + u; }
+    }
+    for (; c < nc; ++c) {
         const float v = P[(size_t)(4 + c) * A + a];
         if (v > best) { best = v; j = c; }
     }

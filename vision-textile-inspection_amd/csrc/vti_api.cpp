@@ -28,9 +28,9 @@ struct vti_ctx {
     const void* last_input = nullptr;
     void* last_proto = nullptr;
     // side streams for the independent branches (proto chain, head levels); created with the weights
-    hipStream_t side[kNumLanes] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t ev_fork[kNumLanes] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t ev_join[kNumLanes] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t side[kNumLanes] = {};
+    hipEvent_t ev_fork[kNumLanes] = {};
+    hipEvent_t ev_join[kNumLanes] = {};
     bool multi_stream = false;
 };
 

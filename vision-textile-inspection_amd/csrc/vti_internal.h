@@ -37,7 +37,7 @@ struct ConvRow {         // fused conv table, Ultralytics order (SURVEY.md Appen
 };
 
 enum OpKind { OP_CONV0, OP_CONV, OP_POOL, OP_UP2, OP_DECODE, OP_FORK, OP_JOIN };
-constexpr int kNumLanes = 4;          // lane 0 = the caller's stream; 1..3 = ctx-owned side streams
+constexpr int kNumLanes = 10;         // lane 0 = the caller's stream; 1..9 = ctx-owned side streams
 
 struct ConvCfg {         // launch geometry chosen at plan time
     int TH = 0, TW = 0;  // output tile (pixels)
