@@ -28,6 +28,9 @@ for r in csv.DictReader(open(f)):
     if k: agg[k].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 nfwd = len(agg["decode_kernel"])            # one decode per forward
 lines = [f"rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline   ({nfwd} forwards incl. calibration/warm-up)",
+         "NOTE: the forward runs its independent branches on side streams, so kernels overlap: per-kernel durations are",
+         "inflated by sharing the chip and their sum exceeds the wall time of a forward (bench.py reports that, ~2.5 ms).",
+         "For non-overlapped per-kernel times run with VTI_SINGLE_STREAM=1.",
          f"{'kernel family':44s} {'calls':>7s} {'avg us':>10s} {'us/forward':>12s}"]
 for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
     lines.append(f"{k:44s} {len(v):7d} {sum(v)/len(v)/1e3:10.1f} {sum(v)/nfwd/1e3:12.1f}")

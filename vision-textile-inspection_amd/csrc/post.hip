@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <type_traits>
 #include <vector>
 
 #include "vti_internal.h"
@@ -451,7 +452,7 @@ __global__ __launch_bounds__(256) void mask_plan_kernel(const float* __restrict_
         for (int tx = tx0; tx <= tx1; ++tx) items[base++] = make_int2((slot * tiles_y + ty) * tiles_x + tx, (lo << 16) | inst);
 }
 
-template <typename T>
+template <typename T, int NM>      // NM = compile-time coefficient count (32), 0 = use the runtime nm
 __global__ __launch_bounds__(256) void masks_kernel(const float* __restrict__ dets, const int* __restrict__ offsets,
                                                     const T* __restrict__ proto, int B, int max_det, int nm, int Hp,
                                                     int Wp, int H, int W, int mode, int packing,
@@ -464,9 +465,10 @@ __global__ __launch_bounds__(256) void masks_kernel(const float* __restrict__ de
     const int n = *nitems;
     for (int it = blockIdx.x; it < n; it += gridDim.x) {
         const int2 itm = items[it];
-        const int item = itm.x;
+        const int item = __builtin_amdgcn_readfirstlane(itm.x);          // block-uniform: keep it scalar
+        const int code = __builtin_amdgcn_readfirstlane(itm.y);
         const int tx = item % tiles_x, ty = (item / tiles_x) % tiles_y, slot = item / (tiles_x * tiles_y);
-        const int b = itm.y >> 16, inst = itm.y & 0xffff;
+        const int b = code >> 16, inst = code & 0xffff;
         __syncthreads();                  // previous iteration is done with the shared tiles
         const int y0 = ty * MT, x0 = tx * MT;
         const int row = 6 + nm;
@@ -492,16 +494,24 @@ __global__ __launch_bounds__(256) void masks_kernel(const float* __restrict__ de
                 if (fc >= bx1 && fc < bx2 && fr >= by1 && fr < by2) {
                     const T* pp = proto + ((size_t)(b * Hp + py) * Wp + px) * nm;
                     float acc = 0.f;
-                    constexpr int PV = 16 / sizeof(T);          // 16-B pieces (nm % 4 == 0, rows 16-B aligned when nm % PV == 0)
-                    if (nm % PV == 0) {
-                        typedef T pvec __attribute__((ext_vector_type(PV)));
+                    constexpr int PV = 16 / sizeof(T);          // 16-B pieces
+                    typedef T pvec __attribute__((ext_vector_type(PV)));
+                    if constexpr (NM > 0) {
+                        // summation order is free here (torch's sgemm sums in its own order anyway)
+#pragma unroll
+                        for (int k = 0; k < NM; k += PV) {
+                            const pvec v = *(const pvec*)(pp + k);
+#pragma unroll
+                            for (int j = 0; j < PV; ++j) acc = __builtin_fmaf(d[6 + k + j], (float)v[j], acc);
+                        }
+                    } else if (nm % PV == 0) {
                         for (int k = 0; k < nm; k += PV) {
                             const pvec v = *(const pvec*)(pp + k);
 #pragma unroll
-                            for (int j = 0; j < PV; ++j) acc = __builtin_fmaf(coef[k + j], (float)v[j], acc);   // summation order is free here
+                            for (int j = 0; j < PV; ++j) acc = __builtin_fmaf(coef[k + j], (float)v[j], acc);
                         }
                     } else {
-                        for (int k = 0; k < nm; ++k) acc += coef[k] * (float)pp[k];
+                        for (int k = 0; k < nm; ++k) acc = __builtin_fmaf(coef[k], (float)pp[k], acc);
                     }
                     v = mode == VTI_MASK_SIGMOID ? 1.0f / (1.0f + expf(-acc)) : acc;
                 }
@@ -514,28 +524,45 @@ __global__ __launch_bounds__(256) void masks_kernel(const float* __restrict__ de
         const int ry = tid >> 2, seg = (tid & 3) * 16;
         const int y = y0 + ry;
         if (y >= H) continue;
-        float sy = sh * ((float)y + 0.5f) - 0.5f; sy = sy < 0.f ? 0.f : sy;
-        const int iy = (int)sy;
+        // F.interpolate(bilinear, align_corners=False) at the fixed 1/4 scale: src = 0.25*(dst+0.5)-0.5 clamped
+        // at 0, so for dst >= 2 the source index is (dst-2)>>2 with fraction {0.125,0.375,0.625,0.875}[(dst-2)&3]
+        // and for dst < 2 it is index 0, fraction 0 (all exact in fp32: the same values the generic formula
+        // gives).  A thread's 16 consecutive output pixels touch at most 6 low-res columns of 2 rows.
+        const int iy = y >= 2 ? (y - 2) >> 2 : 0;
+        const float ly1 = y >= 2 ? 0.125f + 0.25f * (float)((y - 2) & 3) : 0.0f, lyw0 = 1.0f - ly1;
         const int iy1 = iy + (iy < Hp - 1 ? 1 : 0);
-        const float ly1 = sy - (float)iy, lyw0 = 1.0f - ly1;
+        const int xs = x0 + seg;                                   // multiple of 16
+        const int cb = xs >= 2 ? (xs - 2) >> 2 : 0;                // first low-res column this thread needs
+        float r0[6], r1[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            int cc = cb + k;
+            cc = cc < Wp - 1 ? cc : Wp - 1;                        // == min(ix + 1, Wp - 1) for the second tap
+            r0[k] = low[iy - ly0][cc - lx0];
+            r1[k] = low[iy1 - ly0][cc - lx0];
+        }
         unsigned bits = 0;
         unsigned wrd[4] = {0u, 0u, 0u, 0u};   // 16 mask bytes (0/1), little endian
+        // two fully unrolled variants so every register-array index is a compile-time constant
+        auto px16 = [&](auto first) {
+            constexpr bool FIRST = decltype(first)::value;      // xs == 0: pixels 0,1 clamp to column 0
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int x = x0 + seg + j;
-            float sx = sw * ((float)x + 0.5f) - 0.5f; sx = sx < 0.f ? 0.f : sx;
-            const int ix = (int)sx;
-            const int ix1 = ix + (ix < Wp - 1 ? 1 : 0);
-            const float lx1 = sx - (float)ix, lxw0 = 1.0f - lx1;
-            bool on = false;
-            if (x < W) {
-                const float t0 = low[iy - ly0][ix - lx0] * lxw0 + low[iy - ly0][ix1 - lx0] * lx1;
-                const float t1 = low[iy1 - ly0][ix - lx0] * lxw0 + low[iy1 - ly0][ix1 - lx0] * lx1;
-                on = (t0 * lyw0 + t1 * ly1) > thr;
+            for (int j = 0; j < 16; ++j) {
+                const int k0 = FIRST ? (j >= 2 ? (j - 2) >> 2 : 0) : (j + 2) >> 2;
+                const float lx1 = FIRST ? (j >= 2 ? 0.125f + 0.25f * (float)((j - 2) & 3) : 0.0f)
+                                        : 0.125f + 0.25f * (float)((j + 2) & 3);
+                const float lxw0 = 1.0f - lx1;
+                bool on = false;
+                if (xs + j < W) {
+                    const float t0 = r0[k0] * lxw0 + r0[k0 + 1] * lx1;
+                    const float t1 = r1[k0] * lxw0 + r1[k0 + 1] * lx1;
+                    on = (t0 * lyw0 + t1 * ly1) > thr;
+                }
+                wrd[j >> 2] |= (on ? 1u : 0u) << ((j & 3) * 8);
+                bits |= (on ? 1u : 0u) << j;
             }
-            wrd[j >> 2] |= (on ? 1u : 0u) << ((j & 3) * 8);
-            bits |= (on ? 1u : 0u) << j;
-        }
+        };
+        if (xs == 0) px16(std::true_type{}); else px16(std::false_type{});
         if (packing == VTI_PACK_U8) {
             uint8_t* o = masks + ((size_t)slot * H + y) * W + x0 + seg;
             if (x0 + seg + 16 <= W && (W & 15) == 0) {
@@ -573,12 +600,11 @@ hipError_t launch_masks(int dtype, const float* dets, const int* counts, const v
     hipError_t e = hipMemsetAsync(masks, 0, out_bytes, st);
     if (e != hipSuccess) return e;
     const int grid = 256 * 8;     // persistent blocks walk the work list
-    if (dtype == VTI_F16)
-        hipLaunchKernelGGL(masks_kernel<half_t>, dim3(grid), dim3(256), 0, st, dets, offsets, (const half_t*)proto, B, max_det, nm,
-                           Hp, Wp, H, W, mode, packing, masks, items, nitems);
-    else
-        hipLaunchKernelGGL(masks_kernel<float>, dim3(grid), dim3(256), 0, st, dets, offsets, (const float*)proto, B, max_det, nm,
-                           Hp, Wp, H, W, mode, packing, masks, items, nitems);
+#define VTI_MASKS(TT, NMV) hipLaunchKernelGGL((masks_kernel<TT, NMV>), dim3(grid), dim3(256), 0, st, dets, offsets, (const TT*)proto, \
+                                                B, max_det, nm, Hp, Wp, H, W, mode, packing, masks, items, nitems)
+    if (dtype == VTI_F16) { if (nm == 32) VTI_MASKS(half_t, 32); else VTI_MASKS(half_t, 0); }
+    else { if (nm == 32) VTI_MASKS(float, 32); else VTI_MASKS(float, 0); }
+#undef VTI_MASKS
     return hipGetLastError();
 }
 
