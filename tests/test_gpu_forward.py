@@ -44,13 +44,18 @@ def test_layerwise_parity(scale, nc, H, W, B, dtype, tol):
             with pytest.raises(vti_amd.VtiError):
                 eng.debug_conv_output(i, B)
             continue
+        try:
+            got = eng.debug_conv_output(i, B).cpu()
+        except vti_amd.VtiError:
+            # class / coefficient towers whose fused 1x1 writes straight into pred: checked via pred below
+            assert t["fused"] and (".cv3." in t["name"] or ".cv4." in t["name"]), t["name"]
+            continue
         checked += 1
-        got = eng.debug_conv_output(i, B).cpu()
         ref = om.taps[t["name"]]
         assert got.shape == ref.shape and torch.isfinite(ref).all(), t["name"]
         err = (got - ref).abs().max().item()
         assert err <= tol * max(ref.abs().max().item(), 1.0), f"{t['name']}: max|d|={err:.3e} ref max={ref.abs().max():.3e}"
-    assert checked >= len(table) - 10
+    assert checked >= len(table) - 16
     assert pred.shape == opred.shape and torch.isfinite(pred).all()
     if scale != "n":
         return      # m/s random nets carry |logit| ~ 100: only the per-layer bound above is meaningful there

@@ -432,6 +432,24 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvParams p) {
         const int crun2 = (lane >> 4) * 4 * NREP2;      // this lane's consecutive output-channel run
 #pragma unroll
         for (int n = 0; n < NREP2; ++n) bias2[n] = *(const f32x4*)(p.bias2 + crun2 + 4 * n);
+        if (p.pred_mode) {
+            // class scores (exact sigmoid: they are compared with `conf`) / mask coefficients go straight
+            // into pred [B, no, A]: channel-major, so 16 lanes (= 16 anchors) of a tile share a 64-B segment
+#pragma unroll
+            for (int m = 0; m < MREP; ++m) {
+                if (!pvalid[m]) continue;
+                float* o = p.pred + ((size_t)b * p.pred_no + p.pred_cbase) * p.pred_A + p.pred_a0 + opy[m] * p.Wout + opx[m];
+#pragma unroll
+                for (int n = 0; n < NREP2; ++n) {
+                    const f32x4 v = acc2[m][n] + bias2[n];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int ch = crun2 + 4 * n + j;
+                        if (ch < p.Cout2) o[(size_t)ch * p.pred_A] = p.pred_mode == 2 ? 1.0f / (1.0f + expf(-v[j])) : v[j];
+                    }
+                }
+            }
+        } else
 #pragma unroll
         for (int m = 0; m < MREP; ++m) {
             if (!pvalid[m]) continue;

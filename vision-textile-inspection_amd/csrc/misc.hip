@@ -232,6 +232,61 @@ hipError_t launch_decode(const DecodeParams& p, hipStream_t st) {
     return hipGetLastError();
 }
 
+// ---- box-only decode for pred_scatter plans: DFL + dist2bbox on the box tower's logits; class scores and
+// mask coefficients were already written into pred by the towers' fused 1x1 stage.
+__global__ __launch_bounds__(256) void box_decode_kernel(const DecodeParams p, int tiles0, int tiles1, int tiles_per_frame) {
+    __shared__ float tile[DEC_TA * 65];
+    __shared__ float dist4[DEC_TA * 4];
+    const int b = blockIdx.x / tiles_per_frame;
+    int t = blockIdx.x - b * tiles_per_frame;
+    int l = 0;
+    if (t >= tiles0 + tiles1) { l = 2; t -= tiles0 + tiles1; } else if (t >= tiles0) { l = 1; t -= tiles0; }
+    const int W = p.W[l], HW = p.H[l] * W;
+    const int la0 = t * DEC_TA;
+    const int na = min(DEC_TA, HW - la0);
+    const int tid = threadIdx.x;
+    const float* src = p.box[l] + ((size_t)b * HW + la0) * 64;
+    for (int i = tid; i < na * 64; i += 256) tile[(i >> 6) * 65 + (i & 63)] = src[i];
+    __syncthreads();
+    const int a_ = tid >> 2, side = tid & 3;
+    if (a_ < na) {
+        const float* v = tile + a_ * 65 + side * 16;
+        float e[16];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { e[k] = v[k]; mx = fmaxf(mx, e[k]); }
+        float sum = 0.f, dist = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { e[k] = expf(e[k] - mx); sum += e[k]; }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) dist += (e[k] / sum) * (float)k;
+        dist4[a_ * 4 + side] = dist;
+    }
+    __syncthreads();
+    const int no = 4 + p.nc + p.nm;
+    const float st = (float)p.stride[l];
+    const int ch = tid >> 6, a = tid & 63;          // 4 box channels x 64 anchors
+    if (a < na) {
+        const float* r = dist4 + a * 4;
+        const int la = la0 + a;
+        const int gy = la / W, gx = la - gy * W;
+        const float ax = (float)gx + 0.5f, ay = (float)gy + 0.5f;
+        const float x1 = ax - r[0], y1 = ay - r[1], x2 = ax + r[2], y2 = ay + r[3];
+        const float v = ch == 0 ? ((x1 + x2) / 2.0f) * st : ch == 1 ? ((y1 + y2) / 2.0f) * st : ch == 2 ? (x2 - x1) * st : (y2 - y1) * st;
+        p.pred[((size_t)b * no + ch) * p.A + p.a0[l] + la] = v;
+    }
+}
+
+hipError_t launch_box_decode(const DecodeParams& p, hipStream_t st) {
+    if ((long)p.B * p.A == 0) return hipSuccess;
+    if (p.reg_max != 16) return hipErrorInvalidValue;
+    int tiles[3];
+    for (int l = 0; l < 3; ++l) tiles[l] = (p.H[l] * p.W[l] + DEC_TA - 1) / DEC_TA;
+    const int tpf = tiles[0] + tiles[1] + tiles[2];
+    hipLaunchKernelGGL(box_decode_kernel, dim3((unsigned)(p.B * tpf)), dim3(256), 0, st, p, tiles[0], tiles[1], tpf);
+    return hipGetLastError();
+}
+
 // ---- test hook: NHWC channel slice -> f32 NCHW
 template <typename T>
 __global__ void debug_nchw_kernel(const T* src, int B, int H, int W, int C, int ld, int coff, float* dst) {

@@ -318,6 +318,34 @@ std::string Plan::build(const vti_desc& d) {
         }
     }
 
+    // If every class / mask-coefficient tower ends in a fused 1x1, that stage writes its result straight into
+    // pred (sigmoid in the epilogue) and the decode kernel only has to turn the box logits into boxes.
+    {
+        const char* ns = getenv("VTI_NO_PRED_SCATTER");
+        int found = 0;
+        for (Op& op : ops) {
+            if (op.kind != OP_CONV || op.fused < 0) continue;
+            const std::string& nm2 = convs[op.fused].name;      // model.22.cv3.<l>.2 / model.22.cv4.<l>.2
+            if (nm2.rfind("model.22.cv3.", 0) == 0 || nm2.rfind("model.22.cv4.", 0) == 0) ++found;
+        }
+        pred_scatter = found == 6 && !(ns && ns[0] == '1');
+        if (pred_scatter) {
+            int a0[3] = {0, 0, 0};
+            for (int l = 1; l < 3; ++l) a0[l] = a0[l - 1] + levels[l - 1].H * levels[l - 1].W;
+            for (Op& op : ops) {
+                if (op.kind != OP_CONV || op.fused < 0) continue;
+                const std::string& nm2 = convs[op.fused].name;
+                const bool is_cls = nm2.rfind("model.22.cv3.", 0) == 0, is_mc = nm2.rfind("model.22.cv4.", 0) == 0;
+                if (!is_cls && !is_mc) continue;
+                const int l = nm2[13] - '0';
+                op.pred_mode = is_cls ? 2 : 1;
+                op.pred_cbase = is_cls ? 4 : 4 + d.nc;
+                op.pred_a0 = a0[l];
+                conv_out[op.fused].buf = -1;     // lives in pred only
+            }
+        }
+    }
+
     // launch geometry + packed-weight offsets
     macs = 0; fused_params = d.reg_max;
     size_t woff = 0, boff = 0;

@@ -258,6 +258,10 @@ int32_t vti_forward(vti_ctx* c, const uint8_t* input, int32_t B, int32_t swap_rb
                 p.Cout2 = g.gemm_n2; p.ntiles2 = g.ntiles2; p.out2_ld = o2.C; p.out2_coff = op.out2.coff;
                 p.act2 = P.convs[op.fused].kind == 0; p.out2_f32 = op.out2_f32 ? 1 : 0;
                 p.scalar_store2 = (g.gemm_n2 % 4 || o2.C % 4 || op.out2.coff % 4) ? 1 : 0;
+                if (op.pred_mode) {
+                    p.pred = pred; p.pred_mode = op.pred_mode; p.pred_no = 4 + P.desc.nc + P.desc.nm;
+                    p.pred_A = P.num_anchors; p.pred_a0 = op.pred_a0; p.pred_cbase = op.pred_cbase;
+                }
             }
             const bool deconv = r.kind == 2;
             const int ks = deconv ? 1 : r.k, s = deconv ? 1 : r.s;
@@ -296,7 +300,8 @@ int32_t vti_forward(vti_ctx* c, const uint8_t* input, int32_t B, int32_t swap_rb
             }
             p.B = B; p.A = P.num_anchors; p.nc = P.desc.nc; p.nm = P.desc.nm; p.reg_max = P.desc.reg_max;
             p.pred = pred;
-            VTI_HIP(c, launch_decode(p, st), "decode");
+            if (P.pred_scatter) VTI_HIP(c, launch_box_decode(p, st), "box decode");
+            else VTI_HIP(c, launch_decode(p, st), "decode");
             break;
         }
         }

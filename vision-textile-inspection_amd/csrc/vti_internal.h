@@ -61,6 +61,7 @@ struct Op {
     bool has_res = false;
     bool out_f32 = false;
     int fused = -1;      // conv index of a 1x1 conv fused into this op's epilogue (its own op is dropped)
+    int pred_mode = 0, pred_cbase = 0, pred_a0 = 0;   // fused stage writes into pred instead of a head buffer
     View out2;           // where the fused conv writes
     bool out2_f32 = false;
     int lane = 0;        // stream the op is enqueued on (OP_FORK/OP_JOIN: the side lane that starts/finishes)
@@ -80,6 +81,7 @@ struct Plan {
     int proto_buf_c = 0;                 // npr
     View proto_src;                      // input of proto.cv3 (so cv3 writes straight to the caller's proto)
     int num_anchors = 0;
+    bool pred_scatter = false;           // class/coefficient towers write pred directly; decode handles boxes only
     size_t ws_bytes = 0;
     size_t wpk_bytes = 0, bias_floats = 0;
     int64_t macs = 0, fused_params = 0;
@@ -100,6 +102,8 @@ struct ConvParams {
     // fused 1x1 second stage: out2 = act2(W2 . silu(conv + bias) + bias2), never touching HBM in between
     const void* w2; const float* bias2; void* out2;
     int Cout2, ntiles2, out2_ld, out2_coff, act2, out2_f32, scalar_store2;
+    // stage-2 output scattered straight into pred [B, no, A] (class scores with sigmoid / mask coefficients)
+    float* pred; int pred_mode /*0 off, 1 raw, 2 sigmoid*/, pred_no, pred_A, pred_a0, pred_cbase;
     unsigned long long* stamps;          // diagnostic build only (VTI_STAMPS): 16 s_memtime slots per workgroup
 };
 
@@ -123,6 +127,7 @@ struct DecodeParams {
     float* pred;                          // [B, 4+nc+nm, A]
 };
 hipError_t launch_decode(const DecodeParams& p, hipStream_t st);
+hipError_t launch_box_decode(const DecodeParams& p, hipStream_t st);   // DFL + dist2bbox only (pred_scatter plans)
 
 hipError_t launch_debug_nchw(int elem_is_f32, const void* src, int B, int H, int W, int C, int ld, int coff,
                              float* dst, hipStream_t st);
