@@ -238,7 +238,7 @@ template <typename V> __device__ __forceinline__ V buf_load16(__amdgpu_buffer_rs
 }
 
 template <typename T, int KS, int S, int NREP, int WN, int NREP2 = 0>
-__global__ __launch_bounds__(256) void conv_kernel(const ConvParams p) {
+__global__ __launch_bounds__(256, 2) void conv_kernel(const ConvParams p) {   // 2 waves/SIMD: VGPR + AGPR <= 256
     using vec = typename Tr<T>::vec;
     constexpr int VEC = Tr<T>::VEC, KC = Tr<T>::KC;
     constexpr int TAPS = KS * KS, PAD = KS / 2;
@@ -307,19 +307,26 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvParams p) {
         const bool ok = pix < npix && (unsigned)y < (unsigned)p.Hin && (unsigned)x < (unsigned)p.Win;
         aoff[u] = ok ? (unsigned)(((y * p.Win + x) * p.in_ld + p.in_coff + q * VEC) * (int)sizeof(T)) : OOB;
     }
+    // NREP == 5 kernels are at the register limit: they fetch the weight pieces synchronously inside commit()
+    // (short-lived registers, L2-resident data) instead of carrying them across the MFMA loop.
+    constexpr bool BPRE = NREP < 5;
     vec ra[AR], rb[BR];
+    auto loadB = [&](int c) {
+        const unsigned sB = (unsigned)(((size_t)c * p.ntiles_n + nt0) * (TAPS * 1024));
+#pragma unroll
+        for (int u = 0; u < BR; ++u)
+            if (tid + u * 256 < NTB * TAPS * 64) rb[u] = buf_load16<vec>(rsB, (unsigned)(tid + u * 256) * 16u, sB);
+    };
     auto issue = [&](int c) {
         const bool qok = c < cvalid;
 #pragma unroll
         for (int u = 0; u < AR; ++u)
             if (pix0 + 64 * u < ((npix + 7) & ~7))
                 ra[u] = buf_load16<vec>(rsA, qok ? aoff[u] : OOB, (unsigned)(c * KC * (int)sizeof(T)));
-        const unsigned sB = (unsigned)(((size_t)c * p.ntiles_n + nt0) * (TAPS * 1024));
-#pragma unroll
-        for (int u = 0; u < BR; ++u)
-            if (tid + u * 256 < NTB * TAPS * 64) rb[u] = buf_load16<vec>(rsB, (unsigned)(tid + u * 256) * 16u, sB);
+        if constexpr (BPRE) loadB(c);
     };
-    auto commit = [&]() {
+    auto commit = [&](int c) {
+        if constexpr (!BPRE) loadB(c);
 #pragma unroll
         for (int u = 0; u < AR; ++u)
             if (pix0 + 64 * u < npix) *(vec*)(smA + ldsA0 + u * 1024) = ra[u];
@@ -331,7 +338,7 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvParams p) {
     issue(0);
     for (int c = 0; c < p.nchunks; ++c) {
         if (c < 2) VTI_STAMP(1 + 5 * c);
-        commit();                           // waits for this chunk's loads, fills LDS
+        commit(c);                          // waits for this chunk's loads, fills LDS
         if (c < 2) VTI_STAMP(3 + 5 * c);
         __syncthreads();
         if (c < 2) VTI_STAMP(4 + 5 * c);
@@ -341,8 +348,12 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvParams p) {
         // whole tap ahead, so LDS latency hides under the 4-5 MFMAs of each step.
         {
             constexpr int NSTEP = TAPS * MREP;
-            vec xq[3];
-            vec wq[2][NREP];
+            // NREP == 5 (80-channel towers) sits at the register limit: it keeps one weight-fragment set and a
+            // 2-deep pixel queue so that two waves still fit per SIMD (VGPR + AGPR <= 256).
+            constexpr int XD = NREP >= 5 ? 2 : 3;          // pixel fragments in flight
+            constexpr int WD = NREP >= 5 ? 1 : 2;          // weight fragment sets
+            vec xq[XD];
+            vec wq[WD][NREP];
             auto ldx = [&](int s_) -> vec {
                 const int tp = s_ / MREP, mm = s_ % MREP;
                 const int toff = ((tp / KS) * PW + (tp % KS)) * 16;
@@ -355,16 +366,17 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvParams p) {
             };
             ldw(0, wq[0]);
             xq[0] = ldx(0);
-            if (NSTEP > 1) xq[1] = ldx(1);
+            if (XD > 2 && NSTEP > 1) xq[1] = ldx(1);
 #pragma unroll
             for (int s_ = 0; s_ < NSTEP; ++s_) {
                 const int tp = s_ / MREP, mm = s_ % MREP;
-                if (s_ + 2 < NSTEP) xq[(s_ + 2) % 3] = ldx(s_ + 2);
-                if (mm == 0 && tp + 1 < TAPS) ldw(tp + 1, wq[(tp + 1) & 1]);
+                if (s_ + XD - 1 < NSTEP) xq[(s_ + XD - 1) % XD] = ldx(s_ + XD - 1);
+                if (WD == 2 && mm == 0 && tp + 1 < TAPS) ldw(tp + 1, wq[(tp + 1) % WD]);
                 __builtin_amdgcn_sched_barrier(0);      // keep the prefetch reads ahead of this step's MFMAs
 #pragma unroll
-                for (int n = 0; n < NREP; ++n) acc[mm][n] = mma(wq[tp & 1][n], xq[s_ % 3], acc[mm][n]);
+                for (int n = 0; n < NREP; ++n) acc[mm][n] = mma(wq[tp % WD][n], xq[s_ % XD], acc[mm][n]);
                 __builtin_amdgcn_sched_barrier(0);
+                if (WD == 1 && mm == MREP - 1 && tp + 1 < TAPS) ldw(tp + 1, wq[0]);   // reload after the tap's last use
             }
         }
         if (c < 2) VTI_STAMP(5 + 5 * c);
@@ -445,7 +457,14 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvParams p) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int ch = crun2 + 4 * n + j;
-                        if (ch < p.Cout2) o[(size_t)ch * p.pred_A] = p.pred_mode == 2 ? 1.0f / (1.0f + expf(-v[j])) : v[j];
+                        if (ch < p.Cout2) {
+                            float r = v[j];
+                            if (p.pred_mode == 2) {     // sigmoid: exact in the fp32 parity engine, hw-rate (~1 ulp f32) in fp16
+                                if constexpr (FAST) r = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(r * -1.4426950408889634f));
+                                else r = 1.0f / (1.0f + expf(-r));
+                            }
+                            o[(size_t)ch * p.pred_A] = r;
+                        }
                     }
                 }
             }
