@@ -172,6 +172,31 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc)[
         }
         return;
     }
+    if constexpr (sizeof(T) == 2 && NREP % 2 == 0) {
+        if (p.deconv_c && !p.scalar_store && !p.out_f32 && !p.has_res) {
+            // ConvTranspose2d(2,2): this lane's whole channel run lies in ONE (dy,dx) plane (planner keeps
+            // 16*NREP | Cout), so it goes out as 16-byte stores to output pixel (2y+dy, 2x+dx)
+            const int qd = crun / p.deconv_c, co = crun - qd * p.deconv_c;
+#pragma unroll
+            for (int m = 0; m < MREP; ++m) {
+                if (!pvalid[m] || crun >= p.Cout) continue;
+                const size_t opix = ((size_t)(b * 2 * p.Hout + 2 * opy[m] + (qd >> 1))) * (2 * p.Wout) + 2 * opx[m] + (qd & 1);
+                T* op = (T*)p.out + opix * p.out_ld + p.out_coff + co;
+#pragma unroll
+                for (int n = 0; n < NREP; n += 2) {
+                    half8 hv;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float a0 = acc[m][n][j] + bias_r[n][j], a1 = acc[m][n + 1][j] + bias_r[n + 1][j];
+                        if (p.act) { a0 = silu<FAST>(a0); a1 = silu<FAST>(a1); }
+                        hv[j] = (half_t)a0; hv[4 + j] = (half_t)a1;
+                    }
+                    *(half8*)(op + 4 * n) = hv;
+                }
+            }
+            return;
+        }
+    }
     // general case: fp32 head outputs, ragged channel counts (scalar stores), ConvTranspose scatter
 #pragma unroll
     for (int m = 0; m < MREP; ++m) {
