@@ -38,15 +38,26 @@ CASES = [
     (2, 2, 2, 192, 192, 6, 5, (0, 0), {}),                      # m-scale proto upsample
     (1, 1, 1, 32, 32, 16, 20, (1, 2), {"in_coff": 16, "in_ld": 64, "out_coff": 32, "out_ld": 96}),   # concat slices
     (3, 1, 1, 32, 48, 12, 12, (1, 3), {"in_coff": 32, "in_ld": 64}),
+    # persistent LDS-DMA kernel (conv_pk.hip): W >= 20
+    (3, 1, 1, 64, 64, 40, 40, (1, 4), {"res": True}),            # two stationary weight chunks + residual
+    (3, 1, 1, 32, 32, 44, 60, (0, 0), {"in_coff": 32, "in_ld": 64, "out_coff": 32, "out_ld": 96}),   # slices, ragged rows
+    (3, 1, 1, 96, 64, 16, 40, (1, 4), {}),                       # three chunks: streamed weights
+    (3, 1, 1, 32, 32, 80, 80, (1, 2), {"pk_wgs": 8}),            # 5 tiles per workgroup, one chunk
+    (3, 1, 1, 64, 64, 80, 40, (1, 4), {"pk_wgs": 8, "res": True}),   # tile chain with two chunks per tile
+    (3, 1, 1, 80, 80, 48, 40, (1, 5), {"pk_wgs": 3}),            # odd chunk count across tile seams, no XCD ranges
+    (3, 1, 1, 128, 128, 40, 40, (2, 2), {"pk_wgs": 8}),          # waves split along Cout, two n-groups
+    (3, 1, 1, 64, 2, 24, 20, (0, 0), {"out_f32": True}),         # generic epilogue from the persistent kernel
 ]
 
 
 @pytest.mark.parametrize("dtype", ["fp16", "fp32"])
 @pytest.mark.parametrize("case", CASES, ids=lambda c: f"k{c[0]}s{c[1]}kind{c[2]}_{c[3]}to{c[4]}_{c[5]}x{c[6]}_wn{c[7][0]}n{c[7][1]}")
-def test_conv_exact_integers(case, dtype):
+def test_conv_exact_integers(case, dtype, monkeypatch):
     need_gpu()
     import vti_amd
     k, s, kind, c1, c2, H, W, (wn, nrep), ex = case
+    if "pk_wgs" in ex:
+        monkeypatch.setenv("VTI_PK_MAX_WGS", str(ex["pk_wgs"]))
     rng = np.random.default_rng(hash((k, s, kind, c1, c2, H, W)) % (2 ** 32))
     B = 2
     in_ld, in_coff = ex.get("in_ld", c1), ex.get("in_coff", 0)
@@ -70,6 +81,8 @@ def test_conv_exact_integers(case, dtype):
     oc = ex.get("out_coff", 0)
     got = out.float().cpu()
     assert torch.equal(got[..., oc:oc + c2], ref), f"cfg={cfg} max|d|={(got[..., oc:oc + c2] - ref).abs().max()}"
+    if k == 3 and s == 1 and W >= 20:
+        assert cfg["pk"], cfg       # these shapes must exercise the persistent kernel
     if oc:      # neighbours of the written channel slice stay untouched
         assert (got[..., :oc] == 0).all() and (got[..., oc + c2:] == 0).all()
 

@@ -19,56 +19,9 @@
 //    straight 1-KiB-per-fragment copy.
 //  * 256 threads = 4 waves; WN of them split N, 4/WN split M; each wave owns a 5 x NREP grid of
 //    16x16 accumulators (80 pixels x 16*NREP channels).
-#include "vti_internal.h"
+#include "conv_dev.h"
 
 namespace vti {
-
-typedef _Float16 half_t;
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-template <typename T> struct Tr;
-template <> struct Tr<half_t> { typedef half8 vec; static constexpr int VEC = 8, KC = 32; };
-template <> struct Tr<float> { typedef f32x4 vec; static constexpr int VEC = 4, KC = 16; };
-
-__device__ __forceinline__ f32x4 mma(half8 w, half8 x, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(w, x, c, 0, 0, 0);
-}
-// f32: lane l feeds k = 4*(l>>4)+i to the i-th 16x16x4 step on both operands, so the k order is
-// a permutation shared by weights and pixels (exact f32 FMA chain either way).
-__device__ __forceinline__ f32x4 mma(f32x4 w, f32x4 x, f32x4 c) {
-    c = __builtin_amdgcn_mfma_f32_16x16x4f32(w[0], x[0], c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x4f32(w[1], x[1], c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x4f32(w[2], x[2], c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x4f32(w[3], x[3], c, 0, 0, 0);
-    return c;
-}
-
-// SiLU.  fp32 engine (parity mode): IEEE exp + division, as the CPU reference computes it.
-// fp16 engine: v_exp_f32 + v_rcp_f32 (each ~1 ulp in f32, far below the fp16 rounding that follows);
-// the accurate form costs ~30 VALU instructions per element and dominated the kernel's issue slots.
-template <bool FAST> __device__ __forceinline__ float silu(float x) {
-    if constexpr (FAST) return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
-    else return x / (1.0f + expf(-x));
-}
-
-constexpr int MREP = 5;
-
-// Diagnostic build (make STAMPS=1 -> libvti_stamps.so, used only by tools/): s_memtime stamps of
-// workgroup phases, written by wave 0 to a buffer nothing else reads.  Compiled out of the product.
-#ifdef VTI_STAMPS
-#define VTI_STAMP(i)                                                                              \
-    do {                                                                                          \
-        if (p.stamps && tid == 0) {                                                               \
-            unsigned long long t_;                                                                \
-            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");            \
-            p.stamps[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 + (i)] = t_;              \
-        }                                                                                         \
-    } while (0)
-#else
-#define VTI_STAMP(i) do { } while (0)
-#endif
 
 __host__ __device__ inline int patch_dim(int t, int ks, int s, int mode) { return mode == 1 ? t : (t - 1) * s + ks; }
 
@@ -84,184 +37,9 @@ size_t conv_lds_bytes(int ks, int stride, int mode, int TH, int TW, int WN, int 
     return 4 * plane + (size_t)WN * NREP * taps * 1024 + raw;
 }
 
-// ---- shared epilogue: bias, SiLU, residual, stores.
-// With the row permutation of weights.cpp, accumulator lane-group g = lane>>4 of a wave holds, over its
-// NREP n-tiles, the 4*NREP CONSECUTIVE output channels crun .. crun+4*NREP-1 of its pixel
-// (tile n, element j <-> channel crun + 4n + j).  fp16 outputs therefore go out as 16-byte stores (two tiles
-// at a time) that tile whole 128-byte lines; residuals are read the same way.
-template <typename T, int NREP>
-__device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc)[MREP][NREP], const bool (&pvalid)[MREP],
-                                              const int (&opy)[MREP], const int (&opx)[MREP], int b, int nt0, int wn,
-                                              int lane) {
-    // Bias (and the residual of a whole pixel) are loaded up front: a load inside the store loop would make
-    // every block wait on vmcnt(0), i.e. on all earlier STORES as well.
-    constexpr bool FAST = sizeof(T) == 2;
-    const int crun = (nt0 + wn * NREP) * 16 + (lane >> 4) * 4 * NREP;
-    f32x4 bias_r[NREP];
-#pragma unroll
-    for (int n = 0; n < NREP; ++n) {
-        const int cb = crun + 4 * n < p.ntiles_n * 16 ? crun + 4 * n : 0;     // bias is padded to whole groups
-        bias_r[n] = *(const f32x4*)(p.bias + cb);
-    }
-    if (!p.scalar_store && !p.out_f32 && !p.deconv_c) {
-        // common case: T output, vector stores, plain NHWC addressing
-        const bool has_res = __builtin_amdgcn_readfirstlane(p.has_res) != 0;
-#pragma unroll
-        for (int m = 0; m < MREP; ++m) {
-            if (!pvalid[m]) continue;
-            const size_t opix = ((size_t)(b * p.Hout + opy[m])) * p.Wout + opx[m];
-            T* op = (T*)p.out + opix * p.out_ld + p.out_coff + crun;
-            f32x4 res_r[NREP];
-            if (has_res) {
-                const T* rp = (const T*)p.res + opix * p.res_ld + p.res_coff + crun;
-#pragma unroll
-                for (int n = 0; n < NREP; ++n) {
-                    res_r[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    if (crun + 4 * n < p.Cout) {
-                        if constexpr (sizeof(T) == 2) {
-                            const half4 r = *(const half4*)(rp + 4 * n);
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) res_r[n][j] = (float)r[j];
-                        } else {
-                            res_r[n] = *(const f32x4*)(rp + 4 * n);
-                        }
-                    }
-                }
-            }
-            f32x4 v[NREP];
-#pragma unroll
-            for (int n = 0; n < NREP; ++n) {
-                v[n] = acc[m][n] + bias_r[n];
-                if (p.act) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[n][j] = silu<FAST>(v[n][j]);
-                }
-                if (has_res) v[n] += res_r[n];
-            }
-            if constexpr (sizeof(T) == 2) {
-                if constexpr (NREP % 2 == 0) {     // runs start 16-B aligned: one 16-byte store per tile pair
-#pragma unroll
-                    for (int n = 0; n < NREP; n += 2) {
-                        if (crun + 4 * n + 8 <= p.Cout) {
-                            half8 hv;
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) { hv[j] = (half_t)v[n][j]; hv[4 + j] = (half_t)v[n + 1][j]; }
-                            *(half8*)(op + 4 * n) = hv;
-                        } else if (crun + 4 * n + 4 <= p.Cout) {
-                            half4 hv;
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) hv[j] = (half_t)v[n][j];
-                            *(half4*)(op + 4 * n) = hv;
-                        }
-                    }
-                } else {
-#pragma unroll
-                    for (int n = 0; n < NREP; ++n) {
-                        if (crun + 4 * n >= p.Cout) continue;
-                        half4 hv;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) hv[j] = (half_t)v[n][j];
-                        *(half4*)(op + 4 * n) = hv;
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int n = 0; n < NREP; ++n)
-                    if (crun + 4 * n < p.Cout) *(f32x4*)(op + 4 * n) = v[n];
-            }
-        }
-        return;
-    }
-    if constexpr (sizeof(T) == 2 && NREP % 2 == 0) {
-        if (p.deconv_c && !p.scalar_store && !p.out_f32 && !p.has_res) {
-            // ConvTranspose2d(2,2): this lane's whole channel run lies in ONE (dy,dx) plane (planner keeps
-            // 16*NREP | Cout), so it goes out as 16-byte stores to output pixel (2y+dy, 2x+dx)
-            const int qd = crun / p.deconv_c, co = crun - qd * p.deconv_c;
-#pragma unroll
-            for (int m = 0; m < MREP; ++m) {
-                if (!pvalid[m] || crun >= p.Cout) continue;
-                const size_t opix = ((size_t)(b * 2 * p.Hout + 2 * opy[m] + (qd >> 1))) * (2 * p.Wout) + 2 * opx[m] + (qd & 1);
-                T* op = (T*)p.out + opix * p.out_ld + p.out_coff + co;
-#pragma unroll
-                for (int n = 0; n < NREP; n += 2) {
-                    half8 hv;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        float a0 = acc[m][n][j] + bias_r[n][j], a1 = acc[m][n + 1][j] + bias_r[n + 1][j];
-                        if (p.act) { a0 = silu<FAST>(a0); a1 = silu<FAST>(a1); }
-                        hv[j] = (half_t)a0; hv[4 + j] = (half_t)a1;
-                    }
-                    *(half8*)(op + 4 * n) = hv;
-                }
-            }
-            return;
-        }
-    }
-    // general case: fp32 head outputs, ragged channel counts (scalar stores), ConvTranspose scatter
-#pragma unroll
-    for (int m = 0; m < MREP; ++m) {
-        if (!pvalid[m]) continue;
-#pragma unroll
-        for (int n = 0; n < NREP; ++n) {
-            const int cout0 = crun + 4 * n;
-            if (cout0 >= p.Cout) continue;
-            f32x4 v = acc[m][n] + bias_r[n];
-            if (p.act) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = silu<FAST>(v[j]);
-            }
-            size_t opix;
-            int co = cout0;
-            if (p.deconv_c) {
-                const int q = cout0 / p.deconv_c;
-                co = cout0 - q * p.deconv_c;
-                opix = ((size_t)(b * 2 * p.Hout + 2 * opy[m] + (q >> 1))) * (2 * p.Wout) + 2 * opx[m] + (q & 1);
-            } else {
-                opix = ((size_t)(b * p.Hout + opy[m])) * p.Wout + opx[m];
-            }
-            if (p.has_res) {
-                const T* rp = (const T*)p.res + opix * p.res_ld + p.res_coff + co;
-                if constexpr (sizeof(T) == 2) {
-                    const half4 r = *(const half4*)rp;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] += (float)r[j];
-                } else {
-                    v += *(const f32x4*)rp;
-                }
-            }
-            const size_t o = opix * p.out_ld + p.out_coff + co;
-            if (p.scalar_store) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (cout0 + j < p.Cout) {
-                        if (p.out_f32) ((float*)p.out)[o + j] = v[j];
-                        else ((T*)p.out)[o + j] = (T)v[j];
-                    }
-                }
-            } else if (p.out_f32 || sizeof(T) == 4) {
-                *(f32x4*)((float*)p.out + o) = v;
-            } else {
-                half4 hv;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) hv[j] = (half_t)v[j];
-                *(half4*)((half_t*)p.out + o) = hv;
-            }
-        }
-    }
-}
-
 // Register-staged operand prefetch: a thread owns up to AR input-patch pieces and BR weight pieces
 // (16 B each) of a chunk.  issue() only starts the loads; commit() writes them to LDS.  The next chunk is
 // issued before the MFMA loop of the current one, so HBM/L2 latency hides under MFMA.
-// Loads are raw buffer loads: 32-bit per-piece offsets computed once per tile, a scalar offset per chunk,
-// and the hardware range check returns zeros for halo pixels outside the image (offset 0xFFFFFFFF).
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
-template <typename V> __device__ __forceinline__ V buf_load16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
-    return __builtin_bit_cast(V, v);
-}
-
 template <typename T, int KS, int S, int NREP, int WN, int NREP2 = 0>
 __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvParams p) {   // 2 waves/SIMD: VGPR + AGPR <= 256
     using vec = typename Tr<T>::vec;
@@ -412,120 +190,8 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvParams p) {   //
     if constexpr (NREP2 == 0) {
         conv_epilogue<T, NREP>(p, acc, pvalid, opy, opx, b, nt0, wn, lane);
     } else {
-        // ---- fused 1x1 second stage on the register tile (WN == 1: this wave holds every mid channel
-        // of its 80 pixels).  silu(acc + bias) in fp16/fp32 IS the MFMA pixel operand of the next GEMM:
-        // lane group g of cout tile n holds channels 16n+4g+j, and the stage-2 weights are packed with
-        // exactly that K order (weights.cpp: pack_conv_stage2), so nothing moves between lanes or LDS.
         static_assert(WN == 1, "fused stage needs the whole Cout in one wave");
-        constexpr bool FAST = sizeof(T) == 2;
-        constexpr int KT = sizeof(T) == 2 ? (NREP + 1) / 2 : NREP;
-        const __amdgpu_buffer_rsrc_t rsW2 = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)p.w2, 0, (int)(KT * p.ntiles2 * 1024), 0x00020000);
-        f32x4 bias1[NREP];
-#pragma unroll
-        for (int n = 0; n < NREP; ++n) bias1[n] = *(const f32x4*)(p.bias + (lane >> 4) * 4 * NREP + 4 * n);
-        f32x4 acc2[MREP][NREP2];
-#pragma unroll
-        for (int m = 0; m < MREP; ++m)
-#pragma unroll
-            for (int n = 0; n < NREP2; ++n) acc2[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int t2 = 0; t2 < KT; ++t2) {
-            vec w2[NREP2];
-#pragma unroll
-            for (int n = 0; n < NREP2; ++n)
-                w2[n] = buf_load16<vec>(rsW2, (unsigned)(((t2 * p.ntiles2 + n) * 64 + lane) * 16), 0u);
-#pragma unroll
-            for (int m = 0; m < MREP; ++m) {
-                vec x;
-                if constexpr (sizeof(T) == 2) {
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const int n1 = 2 * t2 + h;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            float v = 0.f;
-                            if (n1 < NREP) {
-                                v = acc[m][n1 < NREP ? n1 : 0][j] + bias1[n1 < NREP ? n1 : 0][j];
-                                if (p.act) v = silu<FAST>(v);
-                            }
-                            x[h * 4 + j] = (T)v;
-                        }
-                    }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        float v = acc[m][t2][j] + bias1[t2][j];
-                        if (p.act) v = silu<FAST>(v);
-                        x[j] = v;
-                    }
-                }
-#pragma unroll
-                for (int n = 0; n < NREP2; ++n) acc2[m][n] = mma(w2[n], x, acc2[m][n]);
-            }
-        }
-        // second-stage epilogue: bias2 (+SiLU for proto.cv3), T or fp32 output
-        f32x4 bias2[NREP2];
-        const int crun2 = (lane >> 4) * 4 * NREP2;      // this lane's consecutive output-channel run
-#pragma unroll
-        for (int n = 0; n < NREP2; ++n) bias2[n] = *(const f32x4*)(p.bias2 + crun2 + 4 * n);
-        if (p.pred_mode) {
-            // class scores (exact sigmoid: they are compared with `conf`) / mask coefficients go straight
-            // into pred [B, no, A]: channel-major, so 16 lanes (= 16 anchors) of a tile share a 64-B segment
-#pragma unroll
-            for (int m = 0; m < MREP; ++m) {
-                if (!pvalid[m]) continue;
-                float* o = p.pred + ((size_t)b * p.pred_no + p.pred_cbase) * p.pred_A + p.pred_a0 + opy[m] * p.Wout + opx[m];
-#pragma unroll
-                for (int n = 0; n < NREP2; ++n) {
-                    const f32x4 v = acc2[m][n] + bias2[n];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int ch = crun2 + 4 * n + j;
-                        if (ch < p.Cout2) {
-                            float r = v[j];
-                            if (p.pred_mode == 2) {     // sigmoid: exact in the fp32 parity engine, hw-rate (~1 ulp f32) in fp16
-                                if constexpr (FAST) r = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(r * -1.4426950408889634f));
-                                else r = 1.0f / (1.0f + expf(-r));
-                            }
-                            o[(size_t)ch * p.pred_A] = r;
-                        }
-                    }
-                }
-            }
-        } else
-#pragma unroll
-        for (int m = 0; m < MREP; ++m) {
-            if (!pvalid[m]) continue;
-            const size_t o0 = (((size_t)(b * p.Hout + opy[m])) * p.Wout + opx[m]) * p.out2_ld + p.out2_coff;
-#pragma unroll
-            for (int n = 0; n < NREP2; ++n) {
-                const int cout0 = crun2 + 4 * n;
-                if (cout0 >= p.Cout2) continue;
-                f32x4 v = acc2[m][n] + bias2[n];
-                if (p.act2) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = silu<FAST>(v[j]);
-                }
-                const size_t o = o0 + cout0;
-                if (p.scalar_store2) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        if (cout0 + j < p.Cout2) {
-                            if (p.out2_f32) ((float*)p.out2)[o + j] = v[j];
-                            else ((T*)p.out2)[o + j] = (T)v[j];
-                        }
-                    }
-                } else if (p.out2_f32 || sizeof(T) == 4) {
-                    *(f32x4*)((float*)p.out2 + o) = v;
-                } else {
-                    half4 hv;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) hv[j] = (half_t)v[j];
-                    *(half4*)((half_t*)p.out2 + o) = hv;
-                }
-            }
-        }
+        conv_stage2<T, NREP, NREP2>(p, acc, pvalid, opy, opx, b, lane);
     }
     VTI_STAMP(12);
 }
@@ -694,6 +360,7 @@ static hipError_t launch_t(int ks, int stride, int nrep, int mode, const ConvPar
 
 hipError_t launch_conv(int dtype, int ks, int stride, int nrep, int mode, const ConvParams& p, size_t lds_bytes,
                        hipStream_t st) {
+    if (p.pk) return launch_conv_pk(dtype, nrep, p, lds_bytes, st);
     const int NTB = p.WN * nrep;
     dim3 grid((unsigned)(p.B * p.tiles_y * p.tiles_x), (unsigned)((p.ntiles_n + NTB - 1) / NTB));
     if (grid.x == 0) return hipSuccess;

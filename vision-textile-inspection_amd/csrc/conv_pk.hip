@@ -1,0 +1,363 @@
+// Persistent implicit-GEMM 3x3 / stride-1 convolution for gfx950 (MI355X) with LDS-DMA operand prefetch.
+//
+// Same GEMM view, MFMA operand roles, weight packing and epilogue contract as conv.hip (Conv-BN-SiLU rows of
+// the YOLOv8-seg table, SURVEY.md section 8 U2-U5, behind measurement.py:208-210), different schedule:
+//  * One workgroup per CU slot walks a strided list of output tiles (XCD k owns a contiguous range of tiles, so
+//    neighbouring tiles -- which share halo rows -- meet in one L2).  Nothing is re-derived per tile except the
+//    per-lane source offsets of its input patch.
+//  * Operands reach LDS by `buffer_load_dwordx4 ... lds` (no VGPR staging): while the MFMAs of step s run, the
+//    patch (and, for K > 2 chunks, the weight chunk) of step s+1 is already in flight into the other stage buffer;
+//    a step is one (tile, 32-channel chunk) pair, and the chain crosses tile seams, so a tile's first chunk loads
+//    under the previous tile's MFMAs and epilogue.  Out-of-image halo pixels are out-of-range buffer offsets: the
+//    hardware writes zeros.  One raw s_barrier per step; the DMA of the step is waited for with a counted
+//    s_waitcnt that leaves the epilogue's stores (always MREP * NSTM buffer stores, masked by out-of-range
+//    offsets instead of branches) in flight.
+//  * Weights of a conv with K <= 2 chunks are loaded ONCE per workgroup and stay in LDS for all its tiles.
+//  * LDS patch image: pixel-major, one 64-byte slot per pixel and chunk, 24 slots per patch row (20-wide tiles
+//    + halo, padded to a multiple of 8).  A DMA wave-instruction fills 16 consecutive slots from 16 pixels x 64
+//    contiguous bytes of global memory (4 lanes per pixel: whole 64-B segments, not 16-B fragments).  The 16-byte
+//    piece j of slot s holds channel piece j ^ (2 * bit2(s)) -- the swizzle goes on the per-lane SOURCE address,
+//    the LDS image itself is lane-linear -- which makes the MFMA pixel-operand reads (16 consecutive slots per
+//    k-group, ds_read_b128) conflict-free for every tap: the row pitch is a multiple of 8 slots, so bit 2 of a
+//    slot index only depends on the tap's dx, and each lane keeps three precomputed addresses (dx = 0,1,2) with
+//    dy as an immediate offset.
+#include "conv_dev.h"
+
+namespace vti {
+
+constexpr int PK_PWP = 24;        // slots per patch row
+constexpr int PK_TW = 20;         // tile width (pixels)
+constexpr int PK_ROWS = 4;        // tile rows per M-wave: 4 x 20 = 80 pixels = MREP m-tiles
+constexpr int PK_MAXD = 9;        // patch DMA instructions per wave and step (host checks)
+
+size_t conv_pk_lds_bytes(int TH, int WN, int NREP, int nchunks) {
+    const size_t stage = (size_t)(TH + 2) * PK_PWP * 64;
+    return 2 * stage + (size_t)(nchunks > 1 ? 2 : 1) * WN * NREP * 9 * 1024 + (size_t)WN * NREP * 16 * 4;
+}
+
+bool conv_pk_fits(int TH, int WN, int NREP, int nchunks) {
+    if (TH % PK_ROWS) return false;
+    const int nwaves = (TH / PK_ROWS) * WN;
+    if (nwaves < 1 || nwaves > 4) return false;
+    const int ndma = (TH + 2) * PK_PWP / 16;
+    if ((ndma + nwaves - 1) / nwaves > PK_MAXD) return false;
+    return conv_pk_lds_bytes(TH, WN, NREP, nchunks) <= 160 * 1024;
+}
+
+// LDS-DMA: 64 lanes x 16 B from per-lane buffer offsets to LDS [lds_addr, lds_addr + 1 KiB), lane-linear.
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_addr), "v"(voff), "s"(r), "s"(soff) : "memory");
+}
+
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "i"(N) : "memory"); }
+
+template <typename T, int NREP, int WN, int NREP2 = 0>
+__global__ __launch_bounds__(256) void conv3_pk(const ConvParams p) {
+    using vec = typename Tr<T>::vec;
+    constexpr int VEC = Tr<T>::VEC, KC = Tr<T>::KC, ES = (int)sizeof(T);
+    constexpr int TAPS = 9, NTB = WN * NREP;
+    constexpr int WCHUNK = NTB * TAPS * 1024;
+    constexpr unsigned OOB = 0x80000000u;
+    constexpr bool FAST = sizeof(T) == 2;
+    // stores per m-tile in the fast epilogue: fp16 pairs of n-tiles (16 B) when the run is 16-B aligned
+    constexpr int NSTM = sizeof(T) == 2 ? (NREP % 2 == 0 ? NREP / 2 : NREP) : NREP;
+    constexpr int NST = MREP * NSTM;
+    static_assert(NST <= 48, "counted vmcnt");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nwaves = (int)(blockDim.x >> 6);
+    const int wn = wave % WN, wm = wave / WN;
+    const int PH = p.TH + 2;
+    const int stage_bytes = PH * PK_PWP * 64;
+    const int ndma = PH * PK_PWP / 16;
+    const int wbuf_off = 2 * stage_bytes;
+    const int bias_off = wbuf_off + (p.nchunks > 1 ? 2 : 1) * WCHUNK;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const int nt0 = blockIdx.y * NTB;
+    const bool stream_w = p.nchunks > 2;
+
+    // ---- tile-invariant per-lane state
+    // MFMA pixel operand: m-tile m, lane l -> tile pixel pp = 16m + (l & 15) of this wave's 4 x 20 rows
+    int xa[MREP][3], ry[MREP], rx[MREP];
+#pragma unroll
+    for (int m = 0; m < MREP; ++m) {
+        const int pp = m * 16 + (lane & 15);
+        const int py = (pp * 205) >> 12, px = pp - py * PK_TW;      // pp / 20 for pp < 80
+        ry[m] = wm * PK_ROWS + py; rx[m] = px;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int s = ry[m] * PK_PWP + px + dx;
+            xa[m][dx] = (s * 64 + (lane >> 4) * 16) ^ ((s & 4) << 3);
+        }
+    }
+    // patch DMA: instruction i = wave + u * nwaves fills slots 16i .. 16i+15; lane l -> slot 16i + (l >> 2),
+    // 16-B position l & 3, which holds channel piece q (source-side swizzle)
+    const int q = (lane & 3) ^ (((lane >> 4) & 1) << 1);
+    const int cvalid = (p.Cin - q * VEC + KC - 1) / KC;         // chunks in which this lane's channel piece exists
+    int dyx[PK_MAXD];
+#pragma unroll
+    for (int u = 0; u < PK_MAXD; ++u) {
+        const int s = (wave + u * nwaves) * 16 + (lane >> 2);
+        const int py = (int)(((unsigned)s * 2731u) >> 16), px = s - py * PK_PWP;    // s / 24 for s < 4096
+        dyx[u] = px < PK_TW + 2 ? (py << 8) | px : -1;
+    }
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)p.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.wpk, 0, (int)p.wpk_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)p.out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void*)p.res, 0, (int)p.res_bytes, 0x00020000);
+
+    // bias of this workgroup's channels -> LDS (read back as 16-B pieces in the epilogue)
+    for (int i = tid; i < NTB * 16; i += (int)blockDim.x) ((float*)(smem + bias_off))[i] = p.bias[nt0 * 16 + i];
+    __syncthreads();
+
+    // ---- this workgroup's tiles: XCD k (= blockIdx.x & 7) owns tiles [k * per, (k+1) * per)
+    int t, tend, tstride;
+    if (p.pk_xcd) {
+        const int per = (p.pk_tiles + 7) >> 3, k = blockIdx.x & 7;
+        t = k * per + (int)(blockIdx.x >> 3);
+        tend = min((k + 1) * per, p.pk_tiles);
+        tstride = (int)(gridDim.x >> 3);
+    } else {
+        t = blockIdx.x; tend = p.pk_tiles; tstride = (int)gridDim.x;
+    }
+    if (t >= tend) return;
+
+    unsigned voff[PK_MAXD];
+    auto tile_coords = [&](int tt, int& b, int& oy0, int& ox0) {
+        const int tx = tt % p.tiles_x, r = tt / p.tiles_x;
+        const int ty = r % p.tiles_y;
+        b = r / p.tiles_y; oy0 = ty * p.TH; ox0 = tx * PK_TW;
+    };
+    auto setup_voff = [&](int b, int oy0, int ox0) {
+#pragma unroll
+        for (int u = 0; u < PK_MAXD; ++u) {
+            const int y = oy0 - 1 + (dyx[u] >> 8), x = ox0 - 1 + (dyx[u] & 255);
+            const bool ok = dyx[u] >= 0 && (unsigned)y < (unsigned)p.Hin && (unsigned)x < (unsigned)p.Win;
+            voff[u] = ok ? (unsigned)((((b * p.Hin + y) * p.Win + x) * p.in_ld + p.in_coff + q * VEC) * ES) : OOB;
+        }
+    };
+    auto issue_patch = [&](int c, int stage) {
+        const bool qok = c < cvalid;
+        const unsigned dst = lds0 + stage * stage_bytes + wave * 1024;
+#pragma unroll
+        for (int u = 0; u < PK_MAXD; ++u)
+            if (wave + u * nwaves < ndma)
+                dma16(rsA, qok ? voff[u] : OOB, (unsigned)(c * KC * ES), dst + u * nwaves * 1024);
+    };
+    auto issue_weights = [&](int c, int wb) {
+        const unsigned src = (unsigned)(((size_t)c * p.ntiles_n + nt0) * (TAPS * 1024));
+        const unsigned dst = lds0 + wbuf_off + wb * WCHUNK;
+        for (int f = wave; f < NTB * TAPS; f += nwaves) dma16(rsB, (unsigned)lane * 16u, src + f * 1024, dst + f * 1024);
+    };
+
+    int b, oy0, ox0;
+    tile_coords(t, b, oy0, ox0);
+    setup_voff(b, oy0, ox0);
+    issue_patch(0, 0);
+    issue_weights(0, 0);
+    if (p.nchunks == 2) issue_weights(1, 1);
+
+    const bool fast_epi = NREP2 == 0 && !p.scalar_store && !p.out_f32 && !p.deconv_c &&
+                          (sizeof(T) != 2 || NREP % 2 || (p.Cout & 7) == 0);    // a 16-B pair must not straddle Cout
+    bool pend_stores = false;
+    int step = 0;
+    VTI_STAMP(0);
+    while (true) {
+        f32x4 acc[MREP][NREP];
+#pragma unroll
+        for (int m = 0; m < MREP; ++m)
+#pragma unroll
+            for (int n = 0; n < NREP; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int tn = t + tstride;
+        for (int c = 0; c < p.nchunks; ++c, ++step) {
+            const int cur = step & 1;
+            // the DMA of this step was issued one step ago; only the last epilogue's stores are younger
+#ifdef VTI_STAMPS
+            wait_vm<0>();
+#else
+            if (pend_stores) wait_vm<NST>(); else wait_vm<0>();
+#endif
+            pend_stores = false;
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (step < 2) VTI_STAMP(1 + 4 * step);
+            // ---- prefetch the next step into the other stage (its last readers passed the barrier above)
+            if (c + 1 < p.nchunks) {
+                issue_patch(c + 1, cur ^ 1);
+                if (stream_w) issue_weights(c + 1, cur ^ 1);
+            } else if (tn < tend) {
+                int nb, noy, nox;
+                tile_coords(tn, nb, noy, nox);
+                setup_voff(nb, noy, nox);
+                issue_patch(0, cur ^ 1);
+                if (stream_w) issue_weights(0, cur ^ 1);
+            }
+            if (step < 2) VTI_STAMP(2 + 4 * step);
+            // ---- MFMA over the 9 taps of this chunk (software pipelined as in conv.hip)
+            {
+                const char* sx = smem + cur * stage_bytes;
+                const char* sw = smem + wbuf_off + (p.nchunks > 1 ? cur : 0) * WCHUNK + wn * (NREP * TAPS * 1024) + lane * 16;
+                constexpr int NSTEP = TAPS * MREP;
+                constexpr int XD = 3, WD = 2;
+                vec xq[XD];
+                vec wq[WD][NREP];
+                auto ldx = [&](int s_) -> vec {
+                    const int tp = s_ / MREP, mm = s_ % MREP;
+                    return *(const vec*)(sx + xa[mm][tp % 3] + (tp / 3) * (PK_PWP * 64));
+                };
+                auto ldw = [&](int tp, vec (&w)[NREP]) {
+#pragma unroll
+                    for (int n = 0; n < NREP; ++n) w[n] = *(const vec*)(sw + (n * TAPS + tp) * 1024);
+                };
+                ldw(0, wq[0]);
+                xq[0] = ldx(0);
+                xq[1] = ldx(1);
+#pragma unroll
+                for (int s_ = 0; s_ < NSTEP; ++s_) {
+                    const int tp = s_ / MREP, mm = s_ % MREP;
+                    if (s_ + XD - 1 < NSTEP) xq[(s_ + XD - 1) % XD] = ldx(s_ + XD - 1);
+                    if (mm == 0 && tp + 1 < TAPS) ldw(tp + 1, wq[(tp + 1) % WD]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int n = 0; n < NREP; ++n) acc[mm][n] = mma(wq[tp % WD][n], xq[s_ % XD], acc[mm][n]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (step < 2) VTI_STAMP(3 + 4 * step);
+        }
+        VTI_STAMP(11);
+        // ---- epilogue of tile t
+        if (fast_epi) {
+            const int crun = (nt0 + wn * NREP) * 16 + (lane >> 4) * 4 * NREP;
+            const char* sb = smem + bias_off + (wn * NREP * 16 + (lane >> 4) * 4 * NREP) * 4;
+            f32x4 bias_r[NREP];
+#pragma unroll
+            for (int n = 0; n < NREP; ++n) bias_r[n] = *(const f32x4*)(sb + n * 16);
+            const bool has_res = p.has_res != 0;
+#pragma unroll
+            for (int m = 0; m < MREP; ++m) {
+                const int gy = oy0 + ry[m], gx = ox0 + rx[m];
+                const bool pv = gy < p.Hout && gx < p.Wout;
+                const int opix = (b * p.Hout + gy) * p.Wout + gx;
+                const unsigned ob = (unsigned)((opix * p.out_ld + p.out_coff + crun) * ES);
+                f32x4 v[NREP];
+#pragma unroll
+                for (int n = 0; n < NREP; ++n) v[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (has_res) {
+                    const unsigned rb = (unsigned)((opix * p.res_ld + p.res_coff + crun) * ES);
+#pragma unroll
+                    for (int n = 0; n < NREP; ++n) {
+                        const bool cv = pv && crun + 4 * n < p.Cout;
+                        if constexpr (sizeof(T) == 2) {
+                            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                            const u32x2 r2 = __builtin_amdgcn_raw_buffer_load_b64(rsR, cv ? rb + n * 8 : OOB, 0u, 0);
+                            const half4 r = __builtin_bit_cast(half4, r2);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[n][j] = (float)r[j];
+                        } else {
+                            v[n] = buf_load16<f32x4>(rsR, cv ? rb + n * 16 : OOB, 0u);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int n = 0; n < NREP; ++n) {
+                    f32x4 a = acc[m][n] + bias_r[n];
+                    if (p.act) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) a[j] = silu<FAST>(a[j]);
+                    }
+                    v[n] += a;
+                }
+                if constexpr (sizeof(T) == 2 && NREP % 2 == 0) {
+#pragma unroll
+                    for (int n = 0; n < NREP; n += 2) {
+                        half8 hv;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { hv[j] = (half_t)v[n][j]; hv[4 + j] = (half_t)v[n + 1][j]; }
+                        // a pair that straddles Cout (Cout % 8 == 4) falls back to the generic epilogue on the host side
+                        const bool cv = pv && crun + 4 * n + 8 <= p.Cout;
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hv), rsO, cv ? ob + n * 8 : OOB, 0u, 0);
+                    }
+                } else if constexpr (sizeof(T) == 2) {
+                    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+                    for (int n = 0; n < NREP; ++n) {
+                        half4 hv;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) hv[j] = (half_t)v[n][j];
+                        const bool cv = pv && crun + 4 * n < p.Cout;
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hv), rsO, cv ? ob + n * 8 : OOB, 0u, 0);
+                    }
+                } else {
+#pragma unroll
+                    for (int n = 0; n < NREP; ++n) {
+                        const bool cv = pv && crun + 4 * n < p.Cout;
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[n]), rsO, cv ? ob + n * 16 : OOB, 0u, 0);
+                    }
+                }
+            }
+            pend_stores = true;
+        } else {
+            int opy[MREP], opx[MREP];
+            bool pvalid[MREP];
+#pragma unroll
+            for (int m = 0; m < MREP; ++m) {
+                opy[m] = oy0 + ry[m]; opx[m] = ox0 + rx[m];
+                pvalid[m] = opy[m] < p.Hout && opx[m] < p.Wout;
+            }
+            if constexpr (NREP2 == 0) conv_epilogue<T, NREP>(p, acc, pvalid, opy, opx, b, nt0, wn, lane);
+            else conv_stage2<T, NREP, NREP2>(p, acc, pvalid, opy, opx, b, lane);
+        }
+        VTI_STAMP(12);
+        if (tn >= tend) break;
+        t = tn;
+        tile_coords(t, b, oy0, ox0);
+    }
+}
+
+template <typename T, int NREP, int WN, int NREP2 = 0>
+static hipError_t launch_pk_one(const ConvParams& p, dim3 grid, int threads, size_t lds, hipStream_t st) {
+    auto k = conv3_pk<T, NREP, WN, NREP2>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(k, grid, dim3(threads), lds, st, p);
+    return hipGetLastError();
+}
+
+template <typename T>
+static hipError_t launch_pk_t(int nrep, const ConvParams& p, dim3 grid, int threads, size_t lds, hipStream_t st) {
+    if (p.ntiles2 > 0) {
+        if (p.WN != 1) return hipErrorInvalidValue;
+#define VTI_F(N, N2) if (nrep == N && p.ntiles2 == N2) return launch_pk_one<T, N, 1, N2>(p, grid, threads, lds, st);
+        VTI_F(2, 2) VTI_F(3, 2) VTI_F(4, 1) VTI_F(4, 2) VTI_F(4, 4) VTI_F(4, 5) VTI_F(5, 5)
+#undef VTI_F
+        return hipErrorInvalidValue;
+    }
+#define VTI_L(N, W) if (nrep == N && p.WN == W) return launch_pk_one<T, N, W>(p, grid, threads, lds, st);
+    VTI_L(1, 1) VTI_L(2, 1) VTI_L(3, 1) VTI_L(4, 1) VTI_L(5, 1) VTI_L(2, 2) VTI_L(4, 2) VTI_L(2, 4)
+#undef VTI_L
+    return hipErrorInvalidValue;
+}
+
+// grid.x workgroups (p.pk_wgs, a multiple of 8 when p.pk_xcd) x n-groups; (TH/4) * WN waves per workgroup
+hipError_t launch_conv_pk(int dtype, int nrep, const ConvParams& p, size_t lds_bytes, hipStream_t st) {
+    const int NTB = p.WN * nrep;
+    if (p.TH % PK_ROWS || p.TW != PK_TW || !conv_pk_fits(p.TH, p.WN, nrep, p.nchunks)) return hipErrorInvalidValue;
+    if (p.ntiles_n % NTB || p.pk_wgs < 1 || (p.pk_xcd && p.pk_wgs % 8)) return hipErrorInvalidValue;
+    if ((size_t)p.in_bytes >= 0x80000000u || (size_t)p.out_bytes >= 0x80000000u) return hipErrorInvalidValue;
+    if (p.pk_tiles == 0) return hipSuccess;
+    const int threads = (p.TH / PK_ROWS) * p.WN * 64;
+    dim3 grid((unsigned)p.pk_wgs, (unsigned)(p.ntiles_n / NTB));
+    if (dtype == VTI_F16) return launch_pk_t<half_t>(nrep, p, grid, threads, lds_bytes, st);
+    return launch_pk_t<float>(nrep, p, grid, threads, lds_bytes, st);
+}
+
+}  // namespace vti

@@ -95,6 +95,50 @@ struct Builder {
 
 // Pick the launch geometry for one conv.  Templates fix MREP=5 (80 pixels per wave along M);
 // WN in {1,2,4} splits the 4 waves between pixels and couts; the pixel tile is TH x TW.
+// Geometry for the persistent LDS-DMA kernel (conv_pk.hip; 3x3 stride 1): 20-wide tiles of 4 rows per M-wave.
+// Cost model: rounds of tiles per workgroup slot x MFMAs per wave and chunk x waves on the busiest SIMD, with
+// a mild penalty for LDS operand traffic per MFMA (1/NREP + 1/5).
+static bool choose_pk_cfg(const ConvRow& r, int max_batch, ConvCfg& c, int fth, int fwn, int fnrep) {
+    const char* no = getenv("VTI_NO_PK");
+    if (no && no[0] == '1') return false;
+    if (!(r.k == 3 && r.s == 1 && r.kind != 2) || r.w_out < 20) return false;
+    double best = 1e30;
+    bool found = false;
+    const int tiles_x = (r.w_out + 19) / 20;
+    for (int WN = 1; WN <= 4; WN *= 2) {
+        if (fwn && WN != fwn) continue;
+        for (int NREP = 1; NREP <= 5; ++NREP) {
+            if (fnrep && NREP != fnrep) continue;
+            const int NTB = WN * NREP;
+            const int gy = (c.ntiles_n + NTB - 1) / NTB;
+            const double n_eff = (double)c.ntiles_n / (gy * NTB);
+            if (n_eff < 0.74 && !fnrep) continue;
+            for (int NWM = 1; NWM <= 5; ++NWM) {
+                const int TH = 4 * NWM, nwaves = NWM * WN;
+                if (fth && TH != fth) continue;
+                if (nwaves > 4 || !conv_pk_fits(TH, WN, NREP, c.nchunks)) continue;
+                const size_t lds = conv_pk_lds_bytes(TH, WN, NREP, c.nchunks);
+                int wgpc = (int)std::min<size_t>(2, (160 * 1024) / lds);
+                if (nwaves * wgpc > 8) wgpc = 1;
+                const int tiles_y = (r.h_out + TH - 1) / TH;
+                const long NT = (long)max_batch * tiles_y * tiles_x;
+                long G = std::min<long>(NT, 256L * wgpc / gy);
+                if (G >= 8) G &= ~7L;
+                if (G < 1) continue;
+                const long rounds = (NT + G - 1) / G;
+                const int simd_load = (nwaves * wgpc + 3) / 4;
+                const double cost = (double)rounds * NREP * simd_load * (1.0 + 0.5 * (1.0 / NREP + 0.2 - 0.45));
+                if (cost < best) {
+                    best = cost; found = true;
+                    c.TH = TH; c.TW = 20; c.WN = WN; c.NREP = NREP; c.lds = lds; c.pk = 1; c.pk_wgpc = wgpc;
+                }
+            }
+        }
+    }
+    if (found) c.ntiles_n = (c.ntiles_n + c.NREP - 1) / c.NREP * c.NREP;
+    return found;
+}
+
 void choose_conv_cfg(int dtype, const ConvRow& r, bool conv0, int max_batch, ConvCfg& c, int fth, int ftw, int fwn,
                      int fnrep) {
     const bool f16 = dtype == VTI_F16;
@@ -103,6 +147,8 @@ void choose_conv_cfg(int dtype, const ConvRow& r, bool conv0, int max_batch, Con
     c.gemm_n = deconv ? 4 * r.c2 : r.c2;
     c.ntiles_n = (c.gemm_n + 15) / 16;      // rounded up to whole NREP groups once NREP is chosen (below)
     c.nchunks = conv0 ? (32 / KC) : (r.c1 + KC - 1) / KC;
+    c.pk = 0;
+    if (!conv0 && (!ftw || ftw == 20) && (!fth || fth % 4 == 0) && choose_pk_cfg(r, max_batch, c, fth, fwn, fnrep)) return;
     const int ks = deconv ? 1 : r.k, st = deconv ? 1 : r.s;
     const int Ho = deconv ? r.h_in : r.h_out, Wo = deconv ? r.w_in : r.w_out;
     c.TH = c.TW = 0;

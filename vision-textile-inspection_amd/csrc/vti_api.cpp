@@ -186,7 +186,7 @@ static void* buf_ptr(vti_ctx* c, int buf, const void* input, void* proto) {
 }
 
 // One conv launch's parameter block from its table row + geometry + tensor views.
-static void fill_conv_params(ConvParams& p, const ConvRow& r, const ConvCfg& g, int B, const void* in, int in_ld,
+static void fill_conv_params(int conv_elem_size, ConvParams& p, const ConvRow& r, const ConvCfg& g, int B, const void* in, int in_ld,
                              int in_coff, void* out, int out_ld, int out_coff, const void* res, int res_ld,
                              int res_coff, const void* wpk, const float* bias, bool out_f32, int swap_rb) {
     const bool deconv = r.kind == 2;
@@ -213,6 +213,20 @@ static void fill_conv_params(ConvParams& p, const ConvRow& r, const ConvCfg& g, 
     p.rw_magic = (unsigned)((0x100000000ull + RWD - 1) / RWD);
     p.tw_magic = (unsigned)((0x100000000ull + (unsigned)g.TW - 1) / (unsigned)g.TW);
     p.wpk_bytes = (unsigned)packed_conv_bytes(r, conv0, g);
+    if (g.pk) {   // persistent kernel: workgroups along x walk the B * tiles_y * tiles_x tiles
+        const size_t es = conv_elem_size;
+        const size_t ib = (size_t)B * r.h_in * r.w_in * in_ld * es, ob = (size_t)B * p.Hout * p.Wout * out_ld * (out_f32 ? 4 : es);
+        const size_t rb = res ? (size_t)B * p.Hout * p.Wout * res_ld * es : 0;
+        p.pk = (ib < 0x80000000ull && ob < 0x80000000ull && rb < 0x80000000ull) ? 1 : 0;   // 2^31 marks out-of-range lanes
+        p.in_bytes = (unsigned)ib; p.out_bytes = (unsigned)ob; p.res_bytes = (unsigned)rb;
+        p.pk_tiles = B * p.tiles_y * p.tiles_x;
+        const int gy = g.ntiles_n / (g.WN * g.NREP);
+        int G = std::min(p.pk_tiles, std::max(1, 256 * g.pk_wgpc / gy));
+        if (const char* cap = getenv("VTI_PK_MAX_WGS")) G = std::max(1, std::min(G, atoi(cap)));   // tests: force many tiles per workgroup
+        p.pk_xcd = G >= 8 ? 1 : 0;
+        if (p.pk_xcd) G &= ~7;
+        p.pk_wgs = G;
+    }
 }
 
 int32_t vti_forward(vti_ctx* c, const uint8_t* input, int32_t B, int32_t swap_rb, float* pred, void* proto, void* stream) {
@@ -245,7 +259,7 @@ int32_t vti_forward(vti_ctx* c, const uint8_t* input, int32_t B, int32_t swap_rb
             const Buf& ib = P.bufs[op.in.buf];
             const Buf& ob = P.bufs[op.out.buf];
             ConvParams p;
-            fill_conv_params(p, r, g, B, buf_ptr(c, op.in.buf, input, proto), ib.C, op.in.coff,
+            fill_conv_params(P.esize, p, r, g, B, buf_ptr(c, op.in.buf, input, proto), ib.C, op.in.coff,
                              buf_ptr(c, op.out.buf, input, proto), ob.C, op.out.coff,
                              op.has_res ? buf_ptr(c, op.res.buf, input, proto) : nullptr,
                              op.has_res ? P.bufs[op.res.buf].C : 0, op.res.coff,
@@ -427,7 +441,7 @@ int32_t vti_debug_conv2d(int32_t dtype, const void* dev_in, int32_t B, int32_t H
     ConvCfg g;
     choose_conv_cfg(dtype, r, conv0, B, g, tile_h, tile_w, waves_n, nrep);
     if (g.TH == 0) return fail(nullptr, VTI_ERR_ARG, "vti_debug_conv2d: no launch configuration fits");
-    if (cfg_out) { cfg_out[0] = g.TH; cfg_out[1] = g.TW; cfg_out[2] = g.WN; cfg_out[3] = g.NREP; cfg_out[4] = (int32_t)g.lds; }
+    if (cfg_out) { cfg_out[0] = g.TH; cfg_out[1] = g.TW; cfg_out[2] = g.WN; cfg_out[3] = g.NREP; cfg_out[4] = (int32_t)g.lds * (g.pk ? -1 : 1); }   // negative LDS size = persistent kernel
     std::vector<uint8_t> wpk(packed_conv_bytes(r, conv0, g));
     std::vector<float> bias((size_t)g.ntiles_n * 16);
     pack_conv(dtype, r, conv0, g, host_w, host_b, wpk.data(), bias.data());
@@ -442,13 +456,13 @@ int32_t vti_debug_conv2d(int32_t dtype, const void* dev_in, int32_t B, int32_t H
     if (e == hipSuccess) e = hipEventCreate(&e1);
     if (e == hipSuccess) {
         ConvParams p;
-        fill_conv_params(p, r, g, B, dev_in, in_ld, in_coff, dev_out, out_ld, out_coff, dev_res, res_ld, res_coff, d_w, d_b,
+        fill_conv_params(dtype == VTI_F16 ? 2 : 4, p, r, g, B, dev_in, in_ld, in_coff, dev_out, out_ld, out_coff, dev_res, res_ld, res_coff, d_w, d_b,
                          out_f32 != 0, swap_rb);
         const int ks = kind == 2 ? 1 : k, ss = kind == 2 ? 1 : s;
 #ifdef VTI_STAMPS
         {   // diagnostic build: one stamped launch, medians of the phase intervals to stderr
             const int NTB = g.WN * g.NREP;
-            const size_t nwg = (size_t)B * p.tiles_y * p.tiles_x * ((g.ntiles_n + NTB - 1) / NTB);
+            const size_t nwg = (p.pk ? (size_t)p.pk_wgs : (size_t)B * p.tiles_y * p.tiles_x) * ((g.ntiles_n + NTB - 1) / NTB);
             unsigned long long* d_st = nullptr;
             if (hipMalloc((void**)&d_st, nwg * 16 * 8) == hipSuccess) {
                 (void)hipMemset(d_st, 0, nwg * 16 * 8);

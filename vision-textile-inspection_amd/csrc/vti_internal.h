@@ -52,6 +52,8 @@ struct ConvCfg {         // launch geometry chosen at plan time
     // fused second stage (a 1x1 conv applied to this conv's register tile), 0 tiles = none
     int ntiles2 = 0, gemm_n2 = 0;
     size_t wpk_off2 = 0, bias_off2 = 0;
+    // persistent LDS-DMA kernel (conv_pk.hip): TW = 20, TH = 4 * M-waves; wgpc = co-resident workgroups per CU
+    int pk = 0, pk_wgpc = 1;
 };
 
 struct Op {
@@ -104,6 +106,9 @@ struct ConvParams {
     int Cout2, ntiles2, out2_ld, out2_coff, act2, out2_f32, scalar_store2;
     // stage-2 output scattered straight into pred [B, no, A] (class scores with sigmoid / mask coefficients)
     float* pred; int pred_mode /*0 off, 1 raw, 2 sigmoid*/, pred_no, pred_A, pred_a0, pred_cbase;
+    // persistent kernel (conv_pk.hip): tile count, workgroups along x, XCD-contiguous tile ranges, tensor sizes
+    int pk, pk_tiles, pk_wgs, pk_xcd;
+    unsigned in_bytes, out_bytes, res_bytes;
     unsigned long long* stamps;          // diagnostic build only (VTI_STAMPS): 16 s_memtime slots per workgroup
 };
 
@@ -113,6 +118,10 @@ hipError_t launch_conv(int dtype, int ks, int stride, int nrep, int mode, const 
 bool conv_fusable(int nrep, int nrep2);   // is there a (3x3 NREP) + (1x1 NREP2) fused instantiation
 size_t conv_lds_bytes(int ks, int stride, int mode, int TH, int TW, int WN, int NREP);
 bool conv_cfg_fits(int ks, int stride, int mode, int TH, int TW, int WN, int NREP);
+// conv_pk.hip: persistent 3x3/s1 kernel
+hipError_t launch_conv_pk(int dtype, int nrep, const ConvParams& p, size_t lds_bytes, hipStream_t st);
+size_t conv_pk_lds_bytes(int TH, int WN, int NREP, int nchunks);
+bool conv_pk_fits(int TH, int WN, int NREP, int nchunks);
 
 struct PoolParams { const void* in; void* out; int B, H, W, C, ld, in_coff, out_coff; };
 hipError_t launch_sppf_pool(int dtype, const PoolParams& p, hipStream_t st);

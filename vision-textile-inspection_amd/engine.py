@@ -260,4 +260,4 @@ def debug_conv2d(x, w, b, k, s, kind=0, dtype="fp16", res=None, out=None, in_cof
                                 iters, C.byref(ms), cfg, _stream())
     if rc != 0:
         raise _lib.VtiError(rc, lib().vti_last_error(None).decode())
-    return out, ms.value, dict(tile=(cfg[0], cfg[1]), waves_n=cfg[2], nrep=cfg[3], lds=cfg[4])
+    return out, ms.value, dict(tile=(cfg[0], cfg[1]), waves_n=cfg[2], nrep=cfg[3], lds=abs(cfg[4]), pk=cfg[4] < 0)
