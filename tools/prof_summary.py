@@ -9,6 +9,8 @@ last = rows[-per:]
 def short(n):
     m = re.search(r"conv_kernelI(DF16_|f)Li(\d)ELi(\d)ELi(\d)ELi(\d)", n)
     if m: return f"conv<{'h' if m.group(1) != 'f' else 'f'},k{m.group(2)},s{m.group(3)},n{m.group(4)},m{m.group(5)}>"
+    m = re.search(r"conv3_pkI(DF16_|f)Li(\d)ELi(\d)ELi(\d)E", n)
+    if m: return f"pk3<{'h' if m.group(1) != 'f' else 'f'},n{m.group(2)},w{m.group(3)},f{m.group(4)}>"
     m = re.search(r"vti(?:::|\d+)(\w+?)(?:I|E|\()", n)
     return m.group(1) if m else n[:30]
 tot = 0

@@ -37,10 +37,10 @@ size_t conv_pk_lds_bytes(int TH, int WN, int NREP, int nchunks) {
 
 bool conv_pk_fits(int TH, int WN, int NREP, int nchunks) {
     if (TH % PK_ROWS) return false;
-    const int nwaves = (TH / PK_ROWS) * WN;
-    if (nwaves < 1 || nwaves > 4) return false;
+    const int ncomp = (TH / PK_ROWS) * WN;        // compute waves; as many loader waves beside them
+    if (ncomp < 1 || ncomp > 4) return false;
     const int ndma = (TH + 2) * PK_PWP / 16;
-    if ((ndma + nwaves - 1) / nwaves > PK_MAXD) return false;
+    if ((ndma + ncomp - 1) / ncomp > PK_MAXD) return false;
     return conv_pk_lds_bytes(TH, WN, NREP, nchunks) <= 160 * 1024;
 }
 
@@ -54,23 +54,19 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, unsigned voff, u
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "i"(N) : "memory"); }
 
 template <typename T, int NREP, int WN, int NREP2 = 0>
-__global__ __launch_bounds__(256) void conv3_pk(const ConvParams p) {
+__global__ __launch_bounds__(512) void conv3_pk(const ConvParams p) {
     using vec = typename Tr<T>::vec;
     constexpr int VEC = Tr<T>::VEC, KC = Tr<T>::KC, ES = (int)sizeof(T);
     constexpr int TAPS = 9, NTB = WN * NREP;
     constexpr int WCHUNK = NTB * TAPS * 1024;
     constexpr unsigned OOB = 0x80000000u;
     constexpr bool FAST = sizeof(T) == 2;
-    // stores per m-tile in the fast epilogue: fp16 pairs of n-tiles (16 B) when the run is 16-B aligned
-    constexpr int NSTM = sizeof(T) == 2 ? (NREP % 2 == 0 ? NREP / 2 : NREP) : NREP;
-    constexpr int NST = MREP * NSTM;
-    static_assert(NST <= 48, "counted vmcnt");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nwaves = (int)(blockDim.x >> 6);
-    const int wn = wave % WN, wm = wave / WN;
+    const int ncomp = (p.TH / PK_ROWS) * WN;                // compute waves; the other blockDim/64 - ncomp waves load
+    const int nld = (int)(blockDim.x >> 6) - ncomp;
     const int PH = p.TH + 2;
     const int stage_bytes = PH * PK_PWP * 64;
     const int ndma = PH * PK_PWP / 16;
@@ -79,36 +75,6 @@ __global__ __launch_bounds__(256) void conv3_pk(const ConvParams p) {
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
     const int nt0 = blockIdx.y * NTB;
     const bool stream_w = p.nchunks > 2;
-
-    // ---- tile-invariant per-lane state
-    // MFMA pixel operand: m-tile m, lane l -> tile pixel pp = 16m + (l & 15) of this wave's 4 x 20 rows
-    int xa[MREP][3], ry[MREP], rx[MREP];
-#pragma unroll
-    for (int m = 0; m < MREP; ++m) {
-        const int pp = m * 16 + (lane & 15);
-        const int py = (pp * 205) >> 12, px = pp - py * PK_TW;      // pp / 20 for pp < 80
-        ry[m] = wm * PK_ROWS + py; rx[m] = px;
-#pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
-            const int s = ry[m] * PK_PWP + px + dx;
-            xa[m][dx] = (s * 64 + (lane >> 4) * 16) ^ ((s & 4) << 3);
-        }
-    }
-    // patch DMA: instruction i = wave + u * nwaves fills slots 16i .. 16i+15; lane l -> slot 16i + (l >> 2),
-    // 16-B position l & 3, which holds channel piece q (source-side swizzle)
-    const int q = (lane & 3) ^ (((lane >> 4) & 1) << 1);
-    const int cvalid = (p.Cin - q * VEC + KC - 1) / KC;         // chunks in which this lane's channel piece exists
-    int dyx[PK_MAXD];
-#pragma unroll
-    for (int u = 0; u < PK_MAXD; ++u) {
-        const int s = (wave + u * nwaves) * 16 + (lane >> 2);
-        const int py = (int)(((unsigned)s * 2731u) >> 16), px = s - py * PK_PWP;    // s / 24 for s < 4096
-        dyx[u] = px < PK_TW + 2 ? (py << 8) | px : -1;
-    }
-    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)p.in_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.wpk, 0, (int)p.wpk_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)p.out_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void*)p.res, 0, (int)p.res_bytes, 0x00020000);
 
     // bias of this workgroup's channels -> LDS (read back as 16-B pieces in the epilogue)
     for (int i = tid; i < NTB * 16; i += (int)blockDim.x) ((float*)(smem + bias_off))[i] = p.bias[nt0 * 16 + i];
@@ -125,45 +91,101 @@ __global__ __launch_bounds__(256) void conv3_pk(const ConvParams p) {
         t = blockIdx.x; tend = p.pk_tiles; tstride = (int)gridDim.x;
     }
     if (t >= tend) return;
-
-    unsigned voff[PK_MAXD];
     auto tile_coords = [&](int tt, int& b, int& oy0, int& ox0) {
         const int tx = tt % p.tiles_x, r = tt / p.tiles_x;
         const int ty = r % p.tiles_y;
         b = r / p.tiles_y; oy0 = ty * p.TH; ox0 = tx * PK_TW;
     };
-    auto setup_voff = [&](int b, int oy0, int ox0) {
+
+    if (wave >= ncomp) {
+        // =================== loader waves: every LDS-DMA of the workgroup ===================
+        // Step s = (tile, chunk) pair.  DMA(s+1) is issued right after barrier(s) -- the compute waves finished
+        // reading that stage (step s-1) before they arrived at barrier(s) -- and waited for before barrier(s+1).
+        const int lw = wave - ncomp;
+        // piece i = lw + u * nld fills slots 16i .. 16i+15; lane l -> slot 16i + (l >> 2), 16-B position l & 3,
+        // which holds channel piece q (source-side swizzle)
+        const int q = (lane & 3) ^ (((lane >> 4) & 1) << 1);
+        const int cvalid = (p.Cin - q * VEC + KC - 1) / KC;         // chunks in which this lane's channel piece exists
+        int dyx[PK_MAXD];
 #pragma unroll
         for (int u = 0; u < PK_MAXD; ++u) {
-            const int y = oy0 - 1 + (dyx[u] >> 8), x = ox0 - 1 + (dyx[u] & 255);
-            const bool ok = dyx[u] >= 0 && (unsigned)y < (unsigned)p.Hin && (unsigned)x < (unsigned)p.Win;
-            voff[u] = ok ? (unsigned)((((b * p.Hin + y) * p.Win + x) * p.in_ld + p.in_coff + q * VEC) * ES) : OOB;
+            const int s = (lw + u * nld) * 16 + (lane >> 2);
+            const int py = (int)(((unsigned)s * 2731u) >> 16), px = s - py * PK_PWP;    // s / 24 for s < 4096
+            dyx[u] = px < PK_TW + 2 ? (py << 8) | px : -1;
         }
-    };
-    auto issue_patch = [&](int c, int stage) {
-        const bool qok = c < cvalid;
-        const unsigned dst = lds0 + stage * stage_bytes + wave * 1024;
+        const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)p.in_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.wpk, 0, (int)p.wpk_bytes, 0x00020000);
+        unsigned voff[PK_MAXD];
+        auto setup_voff = [&](int tt) {
+            int b, oy0, ox0;
+            tile_coords(tt, b, oy0, ox0);
 #pragma unroll
-        for (int u = 0; u < PK_MAXD; ++u)
-            if (wave + u * nwaves < ndma)
-                dma16(rsA, qok ? voff[u] : OOB, (unsigned)(c * KC * ES), dst + u * nwaves * 1024);
-    };
-    auto issue_weights = [&](int c, int wb) {
-        const unsigned src = (unsigned)(((size_t)c * p.ntiles_n + nt0) * (TAPS * 1024));
-        const unsigned dst = lds0 + wbuf_off + wb * WCHUNK;
-        for (int f = wave; f < NTB * TAPS; f += nwaves) dma16(rsB, (unsigned)lane * 16u, src + f * 1024, dst + f * 1024);
-    };
+            for (int u = 0; u < PK_MAXD; ++u) {
+                const int y = oy0 - 1 + (dyx[u] >> 8), x = ox0 - 1 + (dyx[u] & 255);
+                const bool ok = dyx[u] >= 0 && (unsigned)y < (unsigned)p.Hin && (unsigned)x < (unsigned)p.Win;
+                voff[u] = ok ? (unsigned)((((b * p.Hin + y) * p.Win + x) * p.in_ld + p.in_coff + q * VEC) * ES) : OOB;
+            }
+        };
+        auto issue_patch = [&](int c, int stage) {
+            const bool qok = c < cvalid;
+            const unsigned dst = lds0 + stage * stage_bytes + lw * 1024;
+#pragma unroll
+            for (int u = 0; u < PK_MAXD; ++u)
+                if (lw + u * nld < ndma)
+                    dma16(rsA, qok ? voff[u] : OOB, (unsigned)(c * KC * ES), dst + u * nld * 1024);
+        };
+        auto issue_weights = [&](int c, int wb) {
+            const unsigned src = (unsigned)(((size_t)c * p.ntiles_n + nt0) * (TAPS * 1024));
+            const unsigned dst = lds0 + wbuf_off + wb * WCHUNK;
+            for (int f = lw; f < NTB * TAPS; f += nld) dma16(rsB, (unsigned)lane * 16u, src + f * 1024, dst + f * 1024);
+        };
+        setup_voff(t);
+        issue_patch(0, 0);
+        issue_weights(0, 0);
+        if (p.nchunks == 2) issue_weights(1, 1);
+        int step = 0;
+        while (true) {
+            const int tn = t + tstride;
+            for (int c = 0; c < p.nchunks; ++c, ++step) {
+                wait_vm<0>();
+                __builtin_amdgcn_s_barrier();
+                const int nxt = (step + 1) & 1;
+                if (c + 1 < p.nchunks) {
+                    issue_patch(c + 1, nxt);
+                    if (stream_w) issue_weights(c + 1, nxt);
+                } else if (tn < tend) {
+                    setup_voff(tn);
+                    issue_patch(0, nxt);
+                    if (stream_w) issue_weights(0, nxt);
+                }
+            }
+            if (tn >= tend) break;
+            t = tn;
+        }
+        return;
+    }
 
-    int b, oy0, ox0;
-    tile_coords(t, b, oy0, ox0);
-    setup_voff(b, oy0, ox0);
-    issue_patch(0, 0);
-    issue_weights(0, 0);
-    if (p.nchunks == 2) issue_weights(1, 1);
-
+    // =================== compute waves: MFMA + epilogue ===================
+    const int wn = wave % WN, wm = wave / WN;
+    // MFMA pixel operand: m-tile m, lane l -> tile pixel pp = 16m + (l & 15) of this wave's 4 x 20 rows
+    int xa[MREP][3], ry[MREP], rx[MREP];
+#pragma unroll
+    for (int m = 0; m < MREP; ++m) {
+        const int pp = m * 16 + (lane & 15);
+        const int py = (pp * 205) >> 12, px = pp - py * PK_TW;      // pp / 20 for pp < 80
+        ry[m] = wm * PK_ROWS + py; rx[m] = px;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int s = ry[m] * PK_PWP + px + dx;
+            xa[m][dx] = (s * 64 + (lane >> 4) * 16) ^ ((s & 4) << 3);
+        }
+    }
+    const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)p.out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void*)p.res, 0, (int)p.res_bytes, 0x00020000);
     const bool fast_epi = NREP2 == 0 && !p.scalar_store && !p.out_f32 && !p.deconv_c &&
                           (sizeof(T) != 2 || NREP % 2 || (p.Cout & 7) == 0);    // a 16-B pair must not straddle Cout
-    bool pend_stores = false;
+    int b, oy0, ox0;
+    tile_coords(t, b, oy0, ox0);
     int step = 0;
     VTI_STAMP(0);
     while (true) {
@@ -172,31 +194,11 @@ __global__ __launch_bounds__(256) void conv3_pk(const ConvParams p) {
         for (int m = 0; m < MREP; ++m)
 #pragma unroll
             for (int n = 0; n < NREP; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const int tn = t + tstride;
         for (int c = 0; c < p.nchunks; ++c, ++step) {
             const int cur = step & 1;
-            // the DMA of this step was issued one step ago; only the last epilogue's stores are younger
-#ifdef VTI_STAMPS
-            wait_vm<0>();
-#else
-            if (pend_stores) wait_vm<NST>(); else wait_vm<0>();
-#endif
-            pend_stores = false;
-            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_barrier();               // the loaders waited for DMA(step) before they arrived
             asm volatile("" ::: "memory");
             if (step < 2) VTI_STAMP(1 + 4 * step);
-            // ---- prefetch the next step into the other stage (its last readers passed the barrier above)
-            if (c + 1 < p.nchunks) {
-                issue_patch(c + 1, cur ^ 1);
-                if (stream_w) issue_weights(c + 1, cur ^ 1);
-            } else if (tn < tend) {
-                int nb, noy, nox;
-                tile_coords(tn, nb, noy, nox);
-                setup_voff(nb, noy, nox);
-                issue_patch(0, cur ^ 1);
-                if (stream_w) issue_weights(0, cur ^ 1);
-            }
-            if (step < 2) VTI_STAMP(2 + 4 * step);
             // ---- MFMA over the 9 taps of this chunk (software pipelined as in conv.hip)
             {
                 const char* sx = smem + cur * stage_bytes;
@@ -278,7 +280,6 @@ __global__ __launch_bounds__(256) void conv3_pk(const ConvParams p) {
                         half8 hv;
 #pragma unroll
                         for (int j = 0; j < 4; ++j) { hv[j] = (half_t)v[n][j]; hv[4 + j] = (half_t)v[n + 1][j]; }
-                        // a pair that straddles Cout (Cout % 8 == 4) falls back to the generic epilogue on the host side
                         const bool cv = pv && crun + 4 * n + 8 <= p.Cout;
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hv), rsO, cv ? ob + n * 8 : OOB, 0u, 0);
                     }
@@ -300,7 +301,6 @@ __global__ __launch_bounds__(256) void conv3_pk(const ConvParams p) {
                     }
                 }
             }
-            pend_stores = true;
         } else {
             int opy[MREP], opx[MREP];
             bool pvalid[MREP];
@@ -313,6 +313,7 @@ __global__ __launch_bounds__(256) void conv3_pk(const ConvParams p) {
             else conv_stage2<T, NREP, NREP2>(p, acc, pvalid, opy, opx, b, lane);
         }
         VTI_STAMP(12);
+        const int tn = t + tstride;
         if (tn >= tend) break;
         t = tn;
         tile_coords(t, b, oy0, ox0);
@@ -342,19 +343,23 @@ static hipError_t launch_pk_t(int nrep, const ConvParams& p, dim3 grid, int thre
         return hipErrorInvalidValue;
     }
 #define VTI_L(N, W) if (nrep == N && p.WN == W) return launch_pk_one<T, N, W>(p, grid, threads, lds, st);
-    VTI_L(1, 1) VTI_L(2, 1) VTI_L(3, 1) VTI_L(4, 1) VTI_L(5, 1) VTI_L(2, 2) VTI_L(4, 2) VTI_L(2, 4)
+    VTI_L(1, 1) VTI_L(2, 1) VTI_L(3, 1) VTI_L(4, 1) VTI_L(5, 1) VTI_L(1, 2) VTI_L(2, 2) VTI_L(3, 2) VTI_L(4, 2) VTI_L(1, 4) VTI_L(2, 4)
 #undef VTI_L
     return hipErrorInvalidValue;
 }
 
-// grid.x workgroups (p.pk_wgs, a multiple of 8 when p.pk_xcd) x n-groups; (TH/4) * WN waves per workgroup
+bool conv_pk_instantiated(int nrep, int wn) {
+    return (wn == 1 && nrep >= 1 && nrep <= 5) || (wn == 2 && nrep >= 1 && nrep <= 4) || (wn == 4 && nrep >= 1 && nrep <= 2);
+}
+
+// grid.x workgroups (p.pk_wgs, a multiple of 8 when p.pk_xcd) x n-groups; (TH/4) * WN compute + as many loader waves
 hipError_t launch_conv_pk(int dtype, int nrep, const ConvParams& p, size_t lds_bytes, hipStream_t st) {
     const int NTB = p.WN * nrep;
     if (p.TH % PK_ROWS || p.TW != PK_TW || !conv_pk_fits(p.TH, p.WN, nrep, p.nchunks)) return hipErrorInvalidValue;
     if (p.ntiles_n % NTB || p.pk_wgs < 1 || (p.pk_xcd && p.pk_wgs % 8)) return hipErrorInvalidValue;
     if ((size_t)p.in_bytes >= 0x80000000u || (size_t)p.out_bytes >= 0x80000000u) return hipErrorInvalidValue;
     if (p.pk_tiles == 0) return hipSuccess;
-    const int threads = (p.TH / PK_ROWS) * p.WN * 64;
+    const int threads = 2 * (p.TH / PK_ROWS) * p.WN * 64;   // compute waves + as many loader waves
     dim3 grid((unsigned)p.pk_wgs, (unsigned)(p.ntiles_n / NTB));
     if (dtype == VTI_F16) return launch_pk_t<half_t>(nrep, p, grid, threads, lds_bytes, st);
     return launch_pk_t<float>(nrep, p, grid, threads, lds_bytes, st);

@@ -96,9 +96,12 @@ struct Builder {
 // Pick the launch geometry for one conv.  Templates fix MREP=5 (80 pixels per wave along M);
 // WN in {1,2,4} splits the 4 waves between pixels and couts; the pixel tile is TH x TW.
 // Geometry for the persistent LDS-DMA kernel (conv_pk.hip; 3x3 stride 1): 20-wide tiles of 4 rows per M-wave.
-// Cost model: rounds of tiles per workgroup slot x MFMAs per wave and chunk x waves on the busiest SIMD, with
-// a mild penalty for LDS operand traffic per MFMA (1/NREP + 1/5).
-static bool choose_pk_cfg(const ConvRow& r, int max_batch, ConvCfg& c, int fth, int fwn, int fnrep) {
+// Cost model (seconds, rough): a layer takes max(memory time, compute-wave time) plus a start-up term.
+//  * memory: patch reads incl. halo rows/columns (once per n-group) + output writes at ~5 TB/s;
+//  * compute: per tile and wave nchunks x 45 x NREP MFMAs of 16 cycles + ~1100 x NREP epilogue cycles, times the
+//    waves that share the busiest SIMD, times the rounds of tiles per workgroup slot, at ~1.9 GHz;
+//  * LDS operand reads per MFMA (1/NREP + 1/5) stretch the MFMA phase once they pass ~0.5.
+static bool choose_pk_cfg(int esize, const ConvRow& r, int max_batch, ConvCfg& c, int fth, int fwn, int fnrep) {
     const char* no = getenv("VTI_NO_PK");
     if (no && no[0] == '1') return false;
     if (!(r.k == 3 && r.s == 1 && r.kind != 2) || r.w_out < 20) return false;
@@ -109,25 +112,29 @@ static bool choose_pk_cfg(const ConvRow& r, int max_batch, ConvCfg& c, int fth, 
         if (fwn && WN != fwn) continue;
         for (int NREP = 1; NREP <= 5; ++NREP) {
             if (fnrep && NREP != fnrep) continue;
+            if (!conv_pk_instantiated(NREP, WN)) continue;
             const int NTB = WN * NREP;
             const int gy = (c.ntiles_n + NTB - 1) / NTB;
             const double n_eff = (double)c.ntiles_n / (gy * NTB);
             if (n_eff < 0.74 && !fnrep) continue;
-            for (int NWM = 1; NWM <= 5; ++NWM) {
-                const int TH = 4 * NWM, nwaves = NWM * WN;
+            for (int NWM = 1; NWM <= 4; ++NWM) {
+                const int TH = 4 * NWM, ncomp = NWM * WN;
                 if (fth && TH != fth) continue;
-                if (nwaves > 4 || !conv_pk_fits(TH, WN, NREP, c.nchunks)) continue;
+                if (ncomp > 4 || !conv_pk_fits(TH, WN, NREP, c.nchunks)) continue;
                 const size_t lds = conv_pk_lds_bytes(TH, WN, NREP, c.nchunks);
-                int wgpc = (int)std::min<size_t>(2, (160 * 1024) / lds);
-                if (nwaves * wgpc > 8) wgpc = 1;
+                const int wgpc = (int)std::min<size_t>(2, (160 * 1024) / lds);
                 const int tiles_y = (r.h_out + TH - 1) / TH;
                 const long NT = (long)max_batch * tiles_y * tiles_x;
-                long G = std::min<long>(NT, 256L * wgpc / gy);
+                long G = std::min<long>(NT, std::max(1, 256 * wgpc / gy));
                 if (G >= 8) G &= ~7L;
-                if (G < 1) continue;
                 const long rounds = (NT + G - 1) / G;
-                const int simd_load = (nwaves * wgpc + 3) / 4;
-                const double cost = (double)rounds * NREP * simd_load * (1.0 + 0.5 * (1.0 / NREP + 0.2 - 0.45));
+                const int simd_load = (ncomp * wgpc + 3) / 4;
+                const double lds_reads = 1.0 / NREP + 0.2;
+                const double mfma_cyc = (double)c.nchunks * 45 * NREP * 16 * std::max(1.0, lds_reads / 0.5);
+                const double t_comp = rounds * (mfma_cyc * simd_load + 1100.0 * NREP) / 1.9e9;   // a SIMD partner's MFMAs hide the epilogue
+                const double bytes = (double)NT * ((double)gy * (TH + 2) * 22 * r.c1 + (double)TH * 20 * r.c2) * esize;
+                const double t_mem = bytes / 5.0e12;
+                const double cost = std::max(t_comp, t_mem) + 0.15 * std::min(t_comp, t_mem) + 4e-6;
                 if (cost < best) {
                     best = cost; found = true;
                     c.TH = TH; c.TW = 20; c.WN = WN; c.NREP = NREP; c.lds = lds; c.pk = 1; c.pk_wgpc = wgpc;
@@ -135,12 +142,12 @@ static bool choose_pk_cfg(const ConvRow& r, int max_batch, ConvCfg& c, int fth, 
             }
         }
     }
-    if (found) c.ntiles_n = (c.ntiles_n + c.NREP - 1) / c.NREP * c.NREP;
+    if (found) c.ntiles_n = (c.ntiles_n + c.WN * c.NREP - 1) / (c.WN * c.NREP) * (c.WN * c.NREP);   // whole workgroup n-groups
     return found;
 }
 
 void choose_conv_cfg(int dtype, const ConvRow& r, bool conv0, int max_batch, ConvCfg& c, int fth, int ftw, int fwn,
-                     int fnrep) {
+                     int fnrep, bool allow_pk) {
     const bool f16 = dtype == VTI_F16;
     const int KC = f16 ? 32 : 16;
     const bool deconv = r.kind == 2;
@@ -148,7 +155,7 @@ void choose_conv_cfg(int dtype, const ConvRow& r, bool conv0, int max_batch, Con
     c.ntiles_n = (c.gemm_n + 15) / 16;      // rounded up to whole NREP groups once NREP is chosen (below)
     c.nchunks = conv0 ? (32 / KC) : (r.c1 + KC - 1) / KC;
     c.pk = 0;
-    if (!conv0 && (!ftw || ftw == 20) && (!fth || fth % 4 == 0) && choose_pk_cfg(r, max_batch, c, fth, fwn, fnrep)) return;
+    if (allow_pk && !conv0 && (!ftw || ftw == 20) && (!fth || fth % 4 == 0) && choose_pk_cfg(f16 ? 2 : 4, r, max_batch, c, fth, fwn, fnrep)) return;
     const int ks = deconv ? 1 : r.k, st = deconv ? 1 : r.s;
     const int Ho = deconv ? r.h_in : r.h_out, Wo = deconv ? r.w_in : r.w_out;
     c.TH = c.TW = 0;
@@ -399,7 +406,10 @@ std::string Plan::build(const vti_desc& d) {
         if (op.kind != OP_CONV && op.kind != OP_CONV0) continue;
         const ConvRow& r = convs[op.conv];
         macs += r.macs(); fused_params += r.fused_params();
-        if (op.fused >= 0) choose_conv_cfg(d.dtype, r, false, d.max_batch, op.cfg, 0, 0, 1, r.c2 / 16);   // whole Cout in one wave
+        if (op.fused >= 0) {   // whole Cout in one wave; the per-tile kernel (2 workgroups per CU) hides the long fused epilogue better
+            const char* pf = getenv("VTI_PK_FUSED");
+            choose_conv_cfg(d.dtype, r, false, d.max_batch, op.cfg, 0, 0, 1, r.c2 / 16, pf && pf[0] == '1');
+        }
         else choose_conv_cfg(d.dtype, r, op.kind == OP_CONV0, d.max_batch, op.cfg);
         if (op.cfg.TH == 0) return "no launch configuration for conv " + r.name;
         op.cfg.wpk_off = woff;

@@ -122,6 +122,7 @@ bool conv_cfg_fits(int ks, int stride, int mode, int TH, int TW, int WN, int NRE
 hipError_t launch_conv_pk(int dtype, int nrep, const ConvParams& p, size_t lds_bytes, hipStream_t st);
 size_t conv_pk_lds_bytes(int TH, int WN, int NREP, int nchunks);
 bool conv_pk_fits(int TH, int WN, int NREP, int nchunks);
+bool conv_pk_instantiated(int nrep, int wn);
 
 struct PoolParams { const void* in; void* out; int B, H, W, C, ld, in_coff, out_coff; };
 hipError_t launch_sppf_pool(int dtype, const PoolParams& p, hipStream_t st);
@@ -161,7 +162,7 @@ hipError_t launch_mask_stats(const uint8_t* bitmaps, int n, int H0, int W0, long
 
 // plan.cpp: launch geometry for one conv (tile, wave split, LDS) -- th/tw/wn/nrep > 0 force a choice
 void choose_conv_cfg(int dtype, const ConvRow& r, bool conv0, int max_batch, ConvCfg& c,
-                     int th = 0, int tw = 0, int wn = 0, int nrep = 0);
+                     int th = 0, int tw = 0, int wn = 0, int nrep = 0, bool allow_pk = true);
 // weights.cpp: one conv's weights -> fragment order; dst_w has cfg.nchunks*ntiles_n*taps KiB, dst_b ntiles_n*16 floats
 void pack_conv(int dtype, const ConvRow& r, bool conv0, const ConvCfg& c, const float* w, const float* b,
                uint8_t* dst_w, float* dst_b);
