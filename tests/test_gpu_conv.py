@@ -108,6 +108,30 @@ def test_conv_silu_random(dtype, tol):
     assert err < tol * max(1.0, ref.abs().max().item()), err
 
 
+@pytest.mark.parametrize("shape", [(16, 16, 40, 40, 0, 0), (32, 32, 40, 60, 0, 0), (64, 64, 44, 40, 0, 0), (64, 80, 40, 40, 0, 0),
+                                   (80, 80, 24, 40, 0, 0), (128, 80, 40, 40, 2, 3), (128, 128, 20, 20, 0, 0), (64, 64, 80, 80, 1, 4)],
+                         ids=lambda s: f"{s[0]}to{s[1]}_{s[2]}x{s[3]}_wn{s[4]}n{s[5]}")
+@pytest.mark.parametrize("wgs", [0, 8])
+def test_conv3x3_silu_persistent(shape, wgs, monkeypatch):
+    """3x3/s1 Conv-BN-SiLU without residual: the persistent kernel's interleaved schedule (epilogue arithmetic in the
+    MFMA gaps, bias as accumulator start value), one tile per workgroup and chains of tiles."""
+    need_gpu()
+    import vti_amd
+    c1, c2, H, W, wn, nrep = shape
+    if wgs:
+        monkeypatch.setenv("VTI_PK_MAX_WGS", str(wgs))
+    rng = np.random.default_rng(c1 * 1000 + c2)
+    B = 3
+    x = rng.standard_normal((B, H, W, c1)).astype(np.float32)
+    w = (rng.standard_normal((c2, c1, 3, 3)) / np.sqrt(9 * c1)).astype(np.float32)
+    b = rng.standard_normal(c2).astype(np.float32) * 0.5
+    out, _, cfg = vti_amd.debug_conv2d(torch.from_numpy(x).half().cuda(), w, b, 3, 1, 0, "fp16", waves_n=wn, nrep=nrep)
+    assert cfg["pk"], cfg
+    ref = ref_conv(x, w, b, 3, 1, 0, "fp16").half().float()
+    err = (out.float().cpu() - ref).abs().max().item()
+    assert err < 2e-3 * max(1.0, ref.abs().max().item()), (err, cfg)
+
+
 @pytest.mark.parametrize("dtype,tol", [("fp16", 1e-3), ("fp32", 1e-6)])
 @pytest.mark.parametrize("swap", [False, True])
 def test_stem_conv_u8(dtype, tol, swap):

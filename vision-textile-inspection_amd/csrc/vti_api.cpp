@@ -476,6 +476,9 @@ int32_t vti_debug_conv2d(int32_t dtype, const void* dev_in, int32_t B, int32_t H
                 (void)hipFree(d_st);
                 const char* names[16] = {"start", "c0:top", "c0:A staged", "c0:B staged", "c0:barrier", "c0:mfma done",
                                          "c1:top", "c1:A staged", "c1:B staged", "c1:barrier", "c1:mfma done", "epilogue start", "end", "", "", ""};
+                const char* pkn[16] = {"start", "c0:before barrier", "c0:after barrier", "c0:sub-tile A done", "c0:sub-tile B done",
+                                       "c1:before barrier", "c1:after barrier", "c1:sub-tile A done", "c1:sub-tile B done", "", "", "epilogue start", "end", "", "", ""};
+                if (p.pk) for (int i = 0; i < 16; ++i) names[i] = pkn[i];
                 fprintf(stderr, "[stamps] %zu workgroups; median cycles since previous stamp (100 MHz s_memtime ticks x clock)\n", nwg);
                 int prev = 0;
                 for (int i = 1; i <= 12; ++i) {
