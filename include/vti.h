@@ -83,6 +83,7 @@ typedef struct {
     int32_t waves_n, nrep;       /* waves along Cout, 16-wide cout tiles per wave */
     int32_t lds_bytes;
     int32_t fused;               /* 1: this 1x1 conv runs inside the previous conv's kernel (register-level fusion) */
+    int32_t persistent;          /* 1: persistent LDS-DMA kernel (conv_pk.hip): tile_h/4 * waves_n compute waves + as many loader waves */
 } vti_conv_info;
 
 /* ---- lifetime -------------------------------------------------------------------- */

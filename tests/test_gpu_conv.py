@@ -113,7 +113,7 @@ def test_conv_silu_random(dtype, tol):
                          ids=lambda s: f"{s[0]}to{s[1]}_{s[2]}x{s[3]}_wn{s[4]}n{s[5]}")
 @pytest.mark.parametrize("wgs", [0, 8])
 def test_conv3x3_silu_persistent(shape, wgs, monkeypatch):
-    """3x3/s1 Conv-BN-SiLU without residual: the persistent kernel's interleaved schedule (epilogue arithmetic in the
+    XX
     MFMA gaps, bias as accumulator start value), one tile per workgroup and chains of tiles."""
     need_gpu()
     import vti_amd

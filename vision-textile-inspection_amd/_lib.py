@@ -23,7 +23,7 @@ class VtiConvInfo(C.Structure):
                 ("s", C.c_int32), ("kind", C.c_int32), ("h_in", C.c_int32), ("w_in", C.c_int32),
                 ("h_out", C.c_int32), ("w_out", C.c_int32), ("macs", C.c_int64),
                 ("tile_h", C.c_int32), ("tile_w", C.c_int32), ("waves_n", C.c_int32), ("nrep", C.c_int32),
-                ("lds_bytes", C.c_int32), ("fused", C.c_int32)]
+                ("lds_bytes", C.c_int32), ("fused", C.c_int32), ("persistent", C.c_int32)]
 
 
 class VtiError(RuntimeError):

@@ -89,7 +89,7 @@ int32_t vti_conv_at(const vti_ctx* c, int32_t i, vti_conv_info* o) {
         if (op.kind != OP_CONV && op.kind != OP_CONV0) continue;
         if (op.conv == i) {
             o->tile_h = op.cfg.TH; o->tile_w = op.cfg.TW; o->waves_n = op.cfg.WN; o->nrep = op.cfg.NREP;
-            o->lds_bytes = (int32_t)op.cfg.lds;
+            o->lds_bytes = (int32_t)op.cfg.lds; o->persistent = op.cfg.pk;
         } else if (op.fused == i) {     // runs inside its producer's kernel, on that kernel's geometry
             o->tile_h = op.cfg.TH; o->tile_w = op.cfg.TW; o->waves_n = 1; o->nrep = op.cfg.ntiles2;
             o->lds_bytes = 0; o->fused = 1;

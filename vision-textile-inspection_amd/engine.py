@@ -58,7 +58,7 @@ class Engine:
             out.append(dict(name=info.name.decode(), c1=info.c1, c2=info.c2, k=info.k, s=info.s, kind=info.kind,
                             h_in=info.h_in, w_in=info.w_in, h_out=info.h_out, w_out=info.w_out, macs=info.macs,
                             tile=(info.tile_h, info.tile_w), waves_n=info.waves_n, nrep=info.nrep, lds=info.lds_bytes,
-                            fused=bool(info.fused)))
+                            fused=bool(info.fused), persistent=bool(info.persistent)))
         return out
 
     @property
