@@ -113,8 +113,8 @@ def test_conv_silu_random(dtype, tol):
                          ids=lambda s: f"{s[0]}to{s[1]}_{s[2]}x{s[3]}_wn{s[4]}n{s[5]}")
 @pytest.mark.parametrize("wgs", [0, 8])
 def test_conv3x3_silu_persistent(shape, wgs, monkeypatch):
-    XX
-    MFMA gaps, bias as accumulator start value), one tile per workgroup and chains of tiles."""
+    """3x3/s1 Conv-BN-SiLU without residual through the persistent kernel (every register tile / wave split it is
+    planned with): one tile per workgroup and chains of tiles, ragged rows, channel-group remainders."""
     need_gpu()
     import vti_amd
     c1, c2, H, W, wn, nrep = shape

@@ -35,6 +35,27 @@ template <bool FAST> __device__ __forceinline__ float silu(float x) {
     else return x / (1.0f + expf(-x));
 }
 
+// Four values at once: the multiplies and the add as packed-f32 instructions (v_pk_mul_f32 / v_pk_add_f32), which
+// halves the non-transcendental instruction count of the activation (PMC: the epilogue was VALU-issue bound at
+// ~12 instructions per value).  Same arithmetic per element as silu<FAST>.
+template <bool FAST> __device__ __forceinline__ f32x4 silu4(f32x4 x) {
+    if constexpr (FAST) {
+        const f32x4 y = x * (f32x4){-1.4426950408889634f, -1.4426950408889634f, -1.4426950408889634f, -1.4426950408889634f};
+        f32x4 e;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) e[j] = __builtin_amdgcn_exp2f(y[j]);
+        e = e + (f32x4){1.0f, 1.0f, 1.0f, 1.0f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) e[j] = __builtin_amdgcn_rcpf(e[j]);
+        return x * e;
+    } else {
+        f32x4 r;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[j] = silu<false>(x[j]);
+        return r;
+    }
+}
+
 constexpr int MREP = 5;
 
 // Diagnostic build (make STAMPS=1 -> libvti_stamps.so, used only by tools/): s_memtime stamps of
@@ -100,10 +121,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc)[
 #pragma unroll
             for (int n = 0; n < NREP; ++n) {
                 v[n] = acc[m][n] + bias_r[n];
-                if (p.act) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[n][j] = silu<FAST>(v[n][j]);
-                }
+                if (p.act) v[n] = silu4<FAST>(v[n]);
                 if (has_res) v[n] += res_r[n];
             }
             if constexpr (sizeof(T) == 2) {
@@ -174,10 +192,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc)[
             const int cout0 = crun + 4 * n;
             if (cout0 >= p.Cout) continue;
             f32x4 v = acc[m][n] + bias_r[n];
-            if (p.act) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = silu<FAST>(v[j]);
-            }
+            if (p.act) v = silu4<FAST>(v);
             size_t opix;
             int co = cout0;
             if (p.deconv_c) {
@@ -243,6 +258,73 @@ __device__ __forceinline__ void conv_stage2(const ConvParams& p, f32x4 (&acc)[MR
     f32x4 bias1[NREP];
 #pragma unroll
     for (int n = 0; n < NREP; ++n) bias1[n] = *(const f32x4*)(p.bias + (lane >> 4) * 4 * NREP + 4 * n);
+    if (p.pred_t) {
+        // ---- transposed pred stage: the activated register tile is the MFMA ROW operand and the 1x1 weights the
+        // column operand, so accumulator lane (g = lane >> 4, j = lane & 15) holds pixels 4g..4g+3 of its m-tile for
+        // channel 16n + j.  Those four pixels are consecutive anchors of one row (tile width and map width are
+        // multiples of 4), i.e. ONE 16-byte store into pred [B, no, A] instead of four scattered dwords.
+        f32x4 acc2[MREP][NREP2];
+#pragma unroll
+        for (int m = 0; m < MREP; ++m)
+#pragma unroll
+            for (int n = 0; n < NREP2; ++n) acc2[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t2 = 0; t2 < KT; ++t2) {
+            vec w2[NREP2];
+#pragma unroll
+            for (int n = 0; n < NREP2; ++n)
+                w2[n] = buf_load16<vec>(rsW2, (unsigned)(((t2 * p.ntiles2 + n) * 64 + lane) * 16), 0u);
+#pragma unroll
+            for (int m = 0; m < MREP; ++m) {
+                vec x;
+                if constexpr (sizeof(T) == 2) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int n1 = 2 * t2 + h;
+                        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                        if (n1 < NREP) {
+                            v = acc[m][n1 < NREP ? n1 : 0] + bias1[n1 < NREP ? n1 : 0];
+                            if (p.act) v = silu4<FAST>(v);
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) x[h * 4 + j] = (T)v[j];
+                    }
+                } else {
+                    f32x4 v = acc[m][t2] + bias1[t2];
+                    if (p.act) v = silu4<FAST>(v);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) x[j] = v[j];
+                }
+#pragma unroll
+                for (int n = 0; n < NREP2; ++n) acc2[m][n] = mma(x, w2[n], acc2[m][n]);
+            }
+        }
+        float b2[NREP2];
+#pragma unroll
+        for (int n = 0; n < NREP2; ++n) b2[n] = p.bias2[n * 16 + (lane & 15)];
+        const int src = (lane & 48) | ((lane >> 4) * 4);        // the lane of this 16-group that owns pixel 4g of the m-tile
+#pragma unroll
+        for (int m = 0; m < MREP; ++m) {
+            const int y4 = __shfl(opy[m], src), x4 = __shfl(opx[m], src);
+            const bool ok4 = __shfl((int)pvalid[m], src) != 0;
+            if (!ok4) continue;
+            float* o = p.pred + ((size_t)b * p.pred_no + p.pred_cbase + (lane & 15)) * p.pred_A + p.pred_a0 + y4 * p.Wout + x4;
+#pragma unroll
+            for (int n = 0; n < NREP2; ++n) {
+                if (n * 16 + (lane & 15) >= p.Cout2) continue;
+                f32x4 v = acc2[m][n] + (f32x4){b2[n], b2[n], b2[n], b2[n]};
+                if (p.pred_mode == 2) {         // sigmoid: exact in the fp32 parity engine, hw-rate (~1 ulp f32) in fp16
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if constexpr (FAST) v[j] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v[j] * -1.4426950408889634f));
+                        else v[j] = 1.0f / (1.0f + expf(-v[j]));
+                    }
+                }
+                *(f32x4*)(o + (size_t)n * 16 * p.pred_A) = v;
+            }
+        }
+        return;
+    }
     f32x4 acc2[MREP][NREP2];
 #pragma unroll
     for (int m = 0; m < MREP; ++m)
@@ -261,23 +343,19 @@ __device__ __forceinline__ void conv_stage2(const ConvParams& p, f32x4 (&acc)[MR
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const int n1 = 2 * t2 + h;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        float v = 0.f;
-                        if (n1 < NREP) {
-                            v = acc[m][n1 < NREP ? n1 : 0][j] + bias1[n1 < NREP ? n1 : 0][j];
-                            if (p.act) v = silu<FAST>(v);
-                        }
-                        x[h * 4 + j] = (T)v;
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    if (n1 < NREP) {
+                        v = acc[m][n1 < NREP ? n1 : 0] + bias1[n1 < NREP ? n1 : 0];
+                        if (p.act) v = silu4<FAST>(v);
                     }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) x[h * 4 + j] = (T)v[j];
                 }
             } else {
+                f32x4 v = acc[m][t2] + bias1[t2];
+                if (p.act) v = silu4<FAST>(v);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float v = acc[m][t2][j] + bias1[t2][j];
-                    if (p.act) v = silu<FAST>(v);
-                    x[j] = v;
-                }
+                for (int j = 0; j < 4; ++j) x[j] = v[j];
             }
 #pragma unroll
             for (int n = 0; n < NREP2; ++n) acc2[m][n] = mma(w2[n], x, acc2[m][n]);
@@ -322,10 +400,7 @@ __device__ __forceinline__ void conv_stage2(const ConvParams& p, f32x4 (&acc)[MR
             const int cout0 = crun2 + 4 * n;
             if (cout0 >= p.Cout2) continue;
             f32x4 v = acc2[m][n] + bias2[n];
-            if (p.act2) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = silu<FAST>(v[j]);
-            }
+            if (p.act2) v = silu4<FAST>(v);
             const size_t o = o0 + cout0;
             if (p.scalar_store2) {
 #pragma unroll

@@ -21,6 +21,8 @@
 //    k-group, ds_read_b128) conflict-free for every tap: the row pitch is a multiple of 8 slots, so bit 2 of a
 //    slot index only depends on the tap's dx, and each lane keeps three precomputed addresses (dx = 0,1,2) with
 //    dy as an immediate offset.
+#include <type_traits>
+
 #include "conv_dev.h"
 
 namespace vti {
@@ -239,7 +241,8 @@ __global__ __launch_bounds__(512) void conv3_pk(const ConvParams p) {
             f32x4 bias_r[NREP];
 #pragma unroll
             for (int n = 0; n < NREP; ++n) bias_r[n] = *(const f32x4*)(sb + n * 16);
-            const bool has_res = p.has_res != 0;
+            auto epi = [&](auto has_res_c) {
+            constexpr bool has_res = decltype(has_res_c)::value;
 #pragma unroll
             for (int m = 0; m < MREP; ++m) {
                 const int gy = oy0 + ry[m], gx = ox0 + rx[m];
@@ -247,9 +250,7 @@ __global__ __launch_bounds__(512) void conv3_pk(const ConvParams p) {
                 const int opix = (b * p.Hout + gy) * p.Wout + gx;
                 const unsigned ob = (unsigned)((opix * p.out_ld + p.out_coff + crun) * ES);
                 f32x4 v[NREP];
-#pragma unroll
-                for (int n = 0; n < NREP; ++n) v[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (has_res) {
+                if constexpr (has_res) {
                     const unsigned rb = (unsigned)((opix * p.res_ld + p.res_coff + crun) * ES);
 #pragma unroll
                     for (int n = 0; n < NREP; ++n) {
@@ -268,11 +269,8 @@ __global__ __launch_bounds__(512) void conv3_pk(const ConvParams p) {
 #pragma unroll
                 for (int n = 0; n < NREP; ++n) {
                     f32x4 a = acc[m][n] + bias_r[n];
-                    if (p.act) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) a[j] = silu<FAST>(a[j]);
-                    }
-                    v[n] += a;
+                    if (p.act) a = silu4<FAST>(a);
+                    if constexpr (has_res) v[n] += a; else v[n] = a;
                 }
                 if constexpr (sizeof(T) == 2 && NREP % 2 == 0) {
 #pragma unroll
@@ -301,6 +299,8 @@ __global__ __launch_bounds__(512) void conv3_pk(const ConvParams p) {
                     }
                 }
             }
+            };
+            if (p.has_res) epi(std::true_type{}); else epi(std::false_type{});
         } else {
             int opy[MREP], opx[MREP];
             bool pvalid[MREP];

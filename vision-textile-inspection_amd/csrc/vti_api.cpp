@@ -274,7 +274,7 @@ int32_t vti_forward(vti_ctx* c, const uint8_t* input, int32_t B, int32_t swap_rb
                 p.scalar_store2 = (g.gemm_n2 % 4 || o2.C % 4 || op.out2.coff % 4) ? 1 : 0;
                 if (op.pred_mode) {
                     p.pred = pred; p.pred_mode = op.pred_mode; p.pred_no = 4 + P.desc.nc + P.desc.nm;
-                    p.pred_A = P.num_anchors; p.pred_a0 = op.pred_a0; p.pred_cbase = op.pred_cbase;
+                    p.pred_A = P.num_anchors; p.pred_a0 = op.pred_a0; p.pred_cbase = op.pred_cbase; p.pred_t = op.pred_t;
                 }
             }
             const bool deconv = r.kind == 2;

@@ -64,6 +64,7 @@ struct Op {
     bool out_f32 = false;
     int fused = -1;      // conv index of a 1x1 conv fused into this op's epilogue (its own op is dropped)
     int pred_mode = 0, pred_cbase = 0, pred_a0 = 0;   // fused stage writes into pred instead of a head buffer
+    int pred_t = 0;          // ... with pixels as MFMA rows: a lane owns 4 consecutive ANCHORS of one channel (16-byte stores)
     View out2;           // where the fused conv writes
     bool out2_f32 = false;
     int lane = 0;        // stream the op is enqueued on (OP_FORK/OP_JOIN: the side lane that starts/finishes)
@@ -105,7 +106,7 @@ struct ConvParams {
     const void* w2; const float* bias2; void* out2;
     int Cout2, ntiles2, out2_ld, out2_coff, act2, out2_f32, scalar_store2;
     // stage-2 output scattered straight into pred [B, no, A] (class scores with sigmoid / mask coefficients)
-    float* pred; int pred_mode /*0 off, 1 raw, 2 sigmoid*/, pred_no, pred_A, pred_a0, pred_cbase;
+    float* pred; int pred_mode /*0 off, 1 raw, 2 sigmoid*/, pred_no, pred_A, pred_a0, pred_cbase, pred_t;
     // persistent kernel (conv_pk.hip): tile count, workgroups along x, XCD-contiguous tile ranges, tensor sizes
     int pk, pk_tiles, pk_wgs, pk_xcd;
     unsigned in_bytes, out_bytes, res_bytes;
@@ -168,7 +169,8 @@ void pack_conv(int dtype, const ConvRow& r, bool conv0, const ConvCfg& c, const 
                uint8_t* dst_w, float* dst_b);
 size_t packed_conv_bytes(const ConvRow& r, bool conv0, const ConvCfg& c);
 // fused second stage: the 1x1 conv `r2` packed against the accumulator layout of a producer with nrep1 cout tiles
-void pack_conv_stage2(int dtype, const ConvRow& r2, int nrep1, const float* w, const float* b, uint8_t* dst_w, float* dst_b);
+void pack_conv_stage2(int dtype, const ConvRow& r2, int nrep1, const float* w, const float* b, uint8_t* dst_w, float* dst_b,
+                      bool natural_rows = false);
 size_t packed_stage2_bytes(int dtype, const ConvRow& r2, int nrep1);
 // weights.cpp: parse VTIW1 + pack into MFMA fragment order (host memory)
 std::string pack_weights(const Plan& plan, const void* blob, size_t nbytes,

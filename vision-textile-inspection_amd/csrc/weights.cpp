@@ -83,7 +83,10 @@ size_t packed_stage2_bytes(int dtype, const ConvRow& r2, int nrep1) {
 // so operand element jj of lane group g is mid channel g*4*nrep1 + (2t + (jj>>2))*4 + (jj&3);
 // fp32: one 16-deep step per tile, element jj = g*4*nrep1 + t*4 + jj.  Output rows use the same
 // permutation with nrep2 = ceil(c2/16) (one group).
-void pack_conv_stage2(int dtype, const ConvRow& r2, int nrep1, const float* w, const float* b, uint8_t* dst, float* bd) {
+// natural_rows: output channel of tile n2, fragment row r is 16*n2 + r (the transposed pred stage, where the
+// weights are the MFMA column operand and a lane's column IS its channel).
+void pack_conv_stage2(int dtype, const ConvRow& r2, int nrep1, const float* w, const float* b, uint8_t* dst, float* bd,
+                      bool natural_rows) {
     const bool f16 = dtype == VTI_F16;
     const int kt = f16 ? (nrep1 + 1) / 2 : nrep1, VEC = f16 ? 8 : 4;
     const int nt2 = (r2.c2 + 15) / 16;
@@ -91,7 +94,7 @@ void pack_conv_stage2(int dtype, const ConvRow& r2, int nrep1, const float* w, c
         for (int n2 = 0; n2 < nt2; ++n2)
             for (int lane = 0; lane < 64; ++lane)
                 for (int jj = 0; jj < VEC; ++jj) {
-                    const int g = lane >> 4, co = perm_cout(n2, lane & 15, nt2);
+                    const int g = lane >> 4, co = natural_rows ? n2 * 16 + (lane & 15) : perm_cout(n2, lane & 15, nt2);
                     const int n1 = f16 ? 2 * t + (jj >> 2) : t;
                     const int cm = g * 4 * nrep1 + n1 * 4 + (f16 ? (jj & 3) : jj);
                     const float v = (n1 < nrep1 && co < r2.c2 && cm < r2.c1) ? w[(size_t)co * r2.c1 + cm] : 0.f;
@@ -145,7 +148,8 @@ std::string pack_weights(const Plan& plan, const void* blob, size_t nbytes, std:
 
         if (host_of[i]) {
             const ConvCfg& hc = host_of[i]->cfg;
-            pack_conv_stage2(plan.desc.dtype, r, hc.NREP, w.data(), b.data(), wpk.data() + hc.wpk_off2, bias.data() + hc.bias_off2);
+            pack_conv_stage2(plan.desc.dtype, r, hc.NREP, w.data(), b.data(), wpk.data() + hc.wpk_off2, bias.data() + hc.bias_off2,
+                             host_of[i]->pred_t != 0);
             continue;
         }
         const Op& op = *op_of[i];
