@@ -6,9 +6,9 @@
 
 One step = one pass of the whole predict pipeline (letterbox[identity] -> 76-conv network -> decode ->
 NMS -> mask assembly (bit-packed) -> scale_boxes) over one batch of 64 synthetic 640x640x3 uint8
-frames per GPU, inputs already resident in HBM.  Steps are software-pipelined in two stages (network of
-batch k on the main stream, post-processing of batch k-1 on a second stream); every batch's full output
-is complete before the closing barrier (--no-pipeline runs the stages in series).  N > 1: one process per GPU; frames live on rank 0
+frames per GPU, inputs already resident in HBM.  Network and post-processing run in series on one stream, so the
+forward's HIP-event time is its own (--pipeline overlaps post-processing of batch k-1 with the network of batch k
+on a second stream: ~2 % more frames/s, but the two then share the chip and the per-stage times are no longer separable).  N > 1: one process per GPU; frames live on rank 0
 and every step scatters the next batch / gathers the previous batch's detections + bit-packed masks
 over RCCL (xGMI) on a side stream, overlapped with compute (weak scaling: 64 frames per GPU).
 
@@ -101,7 +101,9 @@ def main():
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exchange", action="store_true", help="N>1: skip the per-step scatter/gather")
-    ap.add_argument("--no-pipeline", action="store_true", help="run post-processing in series with the network")
+    ap.add_argument("--pipeline", action="store_true",
+                    help="overlap post-processing of batch k with the network of batch k+1 on a second stream (+~2 %% frames/s; "
+                         "the forward's HIP-event time then includes the chip time it shares, so the roofline line is quoted in series)")
     args = ap.parse_args()
 
     import vti_amd
@@ -149,7 +151,7 @@ def main():
     # Two-stage software pipeline on one GPU: the network of batch k runs on the main stream while NMS + mask
     # assembly + scale_boxes of batch k-1 run on a second stream (outputs are double-buffered).  The forward
     # fills the chip; post-processing is latency/VALU-bound with few workgroups and hides underneath it.
-    pipelined = not args.no_pipeline
+    pipelined = args.pipeline
     post_stream = torch.cuda.Stream(device=dev) if pipelined else main_stream
     fwd_done = [torch.cuda.Event(), torch.cuda.Event()]
     post_done = [None, None]
@@ -248,7 +250,7 @@ def main():
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / MFMA_PEAK_TFLOPS, 5), "traffic": traffic,
                          "traffic_note": "HBM bytes per forward (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes, profiles/r01_hbm_traffic.json); algorithmic unfused activation bytes = 91.6 MB/frame",
-                         "kernel": f"vti::conv_kernel family ({eng.num_launches} launches per forward incl. stem/pool/upsample/decode; 76 convs, 10 fused into their producer)",
+                         "kernel": f"vti conv family: conv3_pk (persistent LDS-DMA 3x3) + conv_kernel + stem_kernel ({eng.num_launches} launches per forward incl. pool/upsample/decode; 76 convs, 10 fused into their producer)",
                          "flop_per_launch": flops_per_forward, "avg_ms": round(fwd_ms, 4)},
             "stage_ms": {"forward": round(fwd_ms, 4), "nms+masks+scale_boxes": round(post_ms, 4)},
         }

@@ -3,7 +3,7 @@
 out=$1; kern=$2; shift 2
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/$out
-VTI_SINGLE_STREAM=1 rocprofv3 --pmc "$@" --output-format csv -d gpurun_out/$out -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pipeline > gpurun_out/$out.log 2>&1
+VTI_SINGLE_STREAM=1 rocprofv3 --pmc "$@" --output-format csv -d gpurun_out/$out -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/$out.log 2>&1
 python3 - "$kern" "$out" <<'PY'
 import csv, glob, collections, sys
 kern, out = sys.argv[1], sys.argv[2]

@@ -5,13 +5,15 @@
 //  * One workgroup per CU slot walks a strided list of output tiles (XCD k owns a contiguous range of tiles, so
 //    neighbouring tiles -- which share halo rows -- meet in one L2).  Nothing is re-derived per tile except the
 //    per-lane source offsets of its input patch.
-//  * Operands reach LDS by `buffer_load_dwordx4 ... lds` (no VGPR staging): while the MFMAs of step s run, the
-//    patch (and, for K > 2 chunks, the weight chunk) of step s+1 is already in flight into the other stage buffer;
-//    a step is one (tile, 32-channel chunk) pair, and the chain crosses tile seams, so a tile's first chunk loads
-//    under the previous tile's MFMAs and epilogue.  Out-of-image halo pixels are out-of-range buffer offsets: the
-//    hardware writes zeros.  One raw s_barrier per step; the DMA of the step is waited for with a counted
-//    s_waitcnt that leaves the epilogue's stores (always MREP * NSTM buffer stores, masked by out-of-range
-//    offsets instead of branches) in flight.
+//  * A workgroup is (TH/4) * WN COMPUTE waves plus as many LOADER waves.  Loader waves issue every operand load as
+//    `buffer_load_dwordx4 ... lds` (no VGPR staging): while the compute waves run the MFMAs of step s, the patch
+//    (and, for K > 2 chunks, the weight chunk) of step s+1 is in flight into the other stage buffer; a step is one
+//    (tile, 32-channel chunk) pair and the chain crosses tile seams, so a tile's first chunk loads under the previous
+//    tile's MFMAs and epilogue.  Out-of-image halo pixels are out-of-range buffer offsets: the hardware writes zeros.
+//    One raw s_barrier per step: loaders arrive after `s_waitcnt vmcnt(0)` on their own DMA, compute waves after the
+//    step's MFMAs (so the stage about to be refilled has no readers left).  Compute waves never wait on vmcnt: their
+//    stores stay in flight.  (Issuing a 1-KiB DMA piece costs the issuing wave ~130 cycles; with one compute wave per
+//    SIMD that cost has to live in other waves.)
 //  * Weights of a conv with K <= 2 chunks are loaded ONCE per workgroup and stay in LDS for all its tiles.
 //  * LDS patch image: pixel-major, one 64-byte slot per pixel and chunk, 24 slots per patch row (20-wide tiles
 //    + halo, padded to a multiple of 8).  A DMA wave-instruction fills 16 consecutive slots from 16 pixels x 64
