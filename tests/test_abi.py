@@ -36,6 +36,9 @@ def test_plan_matches_oracle_table(lib_built, scale, nc, H, W):
     assert eng.workspace_bytes > 0
     for t in eng.conv_table():      # every conv got a launch geometry that fits the kernel's register tile
         th, tw = t["tile"]
+        if t["persistent"] and tw == 80:        # conv1_pk: th = M-waves of 80 consecutive pixels each
+            assert 1 <= th <= 4 and th * t["waves_n"] <= 4 and 1 <= t["nrep"] <= 5 and t["lds"] <= 160 * 1024
+            continue
         if t["persistent"]:     # conv_pk.hip: 20-wide tiles, 4 rows per M-wave, <= 4 compute waves, up to the whole 160 KiB of LDS
             assert tw == 20 and th % 4 == 0 and (th // 4) * t["waves_n"] <= 4 and 1 <= t["nrep"] <= 5 and t["lds"] <= 160 * 1024
             continue

@@ -322,6 +322,223 @@ __global__ __launch_bounds__(512) void conv3_pk(const ConvParams p) {
     }
 }
 
+// =====================================================================================================
+// Persistent 1x1 convolution (C2f cv1/cv2, SPPF, ConvTranspose2d(2,2) as a 4-way 1x1 GEMM): HBM-bound layers.
+// Same roles as conv3_pk (compute waves + loader waves, LDS-DMA, swizzled 64-B pixel slots), but
+//  * a tile is a run of (compute waves along M) x 80 consecutive pixels of the flattened [B*H*W] index space;
+//  * the stage ring is `pk_depth` deep (up to 8): the loaders run pk_depth-1 steps ahead, so a CU keeps
+//    ~100 KB of loads in flight (Little's law at the ~4.5 us loaded latency measured on the 3x3 kernel) instead
+//    of one 20-KB stage; they wait for the OLDEST stage with a counted s_waitcnt (every loader wave issues the
+//    same number of DMA pieces per step -- surplus pieces are all-lanes-out-of-range writes into a dummy slot);
+//  * weights stay in LDS for the whole launch when all K chunks of the workgroup's n-group fit (`pk_wstat`),
+//    otherwise the chunk of a step travels with its pixels in the ring.
+// One raw s_barrier per (tile, chunk) step.
+template <int N> struct WaitVm { static __device__ __forceinline__ void go(int n) { if (n >= N) wait_vm<N>(); else WaitVm<N - 1>::go(n); } };
+template <> struct WaitVm<0> { static __device__ __forceinline__ void go(int) { wait_vm<0>(); } };
+
+constexpr int PK1_MAXP = 5;       // pixel DMA pieces per loader wave and step (80 px = 5 pieces per M-wave, WN >= 1)
+
+size_t conv1_pk_lds_bytes(int nwm, int WN, int NREP, int nchunks, int depth, int wstat) {
+    const size_t stage = (size_t)nwm * 80 * 64;
+    const size_t wch = (size_t)WN * NREP * 1024;
+    return (size_t)depth * stage + (wstat ? (size_t)nchunks * wch : (size_t)depth * wch) + 1024 /*dummy*/ + (size_t)WN * NREP * 64;
+}
+
+template <typename T, int NREP, int WN>
+__global__ __launch_bounds__(512) void conv1_pk(const ConvParams p) {
+    using vec = typename Tr<T>::vec;
+    constexpr int VEC = Tr<T>::VEC, KC = Tr<T>::KC, ES = (int)sizeof(T);
+    constexpr int NTB = WN * NREP;
+    constexpr int WCH = NTB * 1024;
+    constexpr unsigned OOB = 0x80000000u;
+    constexpr bool FAST = sizeof(T) == 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nwm = p.TH;                                   // compute waves along M (p.TH is reused for it)
+    const int ncomp = nwm * WN;
+    const int nld = (int)(blockDim.x >> 6) - ncomp;
+    const int D = p.pk_depth;
+    const int tile_px = nwm * 80;
+    const int stage_bytes = tile_px * 64;
+    const int npieces = tile_px / 16;
+    const int wbuf_off = D * stage_bytes;
+    const int dummy_off = wbuf_off + (p.pk_wstat ? p.nchunks : D) * WCH;
+    const int bias_off = dummy_off + 1024;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const int nt0 = blockIdx.y * NTB;
+    const int total_px = p.B * p.Hout * p.Wout;
+
+    for (int i = tid; i < NTB * 16; i += (int)blockDim.x) ((float*)(smem + bias_off))[i] = p.bias[nt0 * 16 + i];
+    __syncthreads();
+
+    int t, tend, tstride;
+    if (p.pk_xcd) {
+        const int per = (p.pk_tiles + 7) >> 3, k = blockIdx.x & 7;
+        t = k * per + (int)(blockIdx.x >> 3);
+        tend = min((k + 1) * per, p.pk_tiles);
+        tstride = (int)(gridDim.x >> 3);
+    } else {
+        t = blockIdx.x; tend = p.pk_tiles; tstride = (int)gridDim.x;
+    }
+    if (t >= tend) return;
+    const int ntiles_mine = (tend - t + tstride - 1) / tstride;
+    const int nsteps = ntiles_mine * p.nchunks;
+
+    if (wave >= ncomp) {
+        // =================== loader waves ===================
+        const int lw = wave - ncomp;
+        const int q = (lane & 3) ^ (((lane >> 4) & 1) << 1);            // channel piece of this lane's 16-B position
+        const int cvalid = (p.Cin - q * VEC + KC - 1) / KC;
+        const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)p.in_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.wpk, 0, (int)p.wpk_bytes, 0x00020000);
+        const int ppl = (npieces + nld - 1) / nld;                      // pixel pieces per loader and step (<= PK1_MAXP)
+        const int wpl = p.pk_wstat ? 0 : (NTB + nld - 1) / nld;         // weight pieces per loader and step
+        const int per_step = ppl + wpl;
+        auto issue = [&](int s) {                                       // DMA of step s of this workgroup's chain
+            const int ti = s / p.nchunks, c = s - ti * p.nchunks;
+            const int pix0 = (t + ti * tstride) * tile_px;
+            const int slot = s % D;
+            const bool qok = c < cvalid;
+            const unsigned dst = lds0 + slot * stage_bytes;
+#pragma unroll
+            for (int u = 0; u < PK1_MAXP; ++u) {
+                if (u >= ppl) break;
+                const int piece = lw + u * nld;
+                const int px = pix0 + piece * 16 + (lane >> 2);
+                const bool ok = piece < npieces && px < total_px && qok;
+                const unsigned vo = ok ? (unsigned)((px * p.in_ld + p.in_coff + q * VEC) * ES) : OOB;
+                dma16(rsA, vo, (unsigned)(c * KC * ES), piece < npieces ? dst + piece * 1024 : lds0 + dummy_off);
+            }
+            if (wpl) {
+                const unsigned src = (unsigned)(((size_t)c * p.ntiles_n + nt0) * 1024);
+                const unsigned wd = lds0 + wbuf_off + slot * WCH;
+                for (int u = 0; u < wpl; ++u) {
+                    const int f = lw + u * nld;
+                    dma16(rsB, f < NTB ? (unsigned)lane * 16u : OOB, src + f * 1024, f < NTB ? wd + f * 1024 : lds0 + dummy_off);
+                }
+            }
+        };
+        if (p.pk_wstat) {                                               // every chunk of this n-group, once
+            for (int f = lw; f < p.nchunks * NTB; f += nld) {
+                const int c = f / NTB, n = f - c * NTB;
+                dma16(rsB, (unsigned)lane * 16u, (unsigned)(((size_t)c * p.ntiles_n + nt0 + n) * 1024), lds0 + wbuf_off + f * 1024);
+            }
+        }
+        const int ahead = min(D - 1, nsteps);
+        for (int s = 0; s < ahead; ++s) issue(s);
+        for (int s = 0; s < nsteps; ++s) {
+            // steps s+1 .. min(s+D-2, nsteps-1) may stay in flight; everything older (incl. the stationary weights) is waited for
+            const int inflight = min(D - 2, nsteps - 1 - s);
+            WaitVm<63>::go(min(63, inflight * per_step));
+            __builtin_amdgcn_s_barrier();
+            if (s + D - 1 < nsteps) issue(s + D - 1);                   // refills the slot the compute waves left before this barrier
+        }
+        return;
+    }
+
+    // =================== compute waves ===================
+    const int wn = wave % WN, wm = wave / WN;
+    int xa[MREP];
+#pragma unroll
+    for (int m = 0; m < MREP; ++m) {
+        const int sl = wm * 80 + m * 16 + (lane & 15);
+        xa[m] = (sl * 64 + (lane >> 4) * 16) ^ ((sl & 4) << 3);
+    }
+    const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)p.out_bytes, 0x00020000);
+    const bool fast_epi = !p.scalar_store && !p.out_f32 && !p.deconv_c && !p.has_res &&
+                          (sizeof(T) != 2 || NREP % 2 || (p.Cout & 7) == 0);
+    const int crun = (nt0 + wn * NREP) * 16 + (lane >> 4) * 4 * NREP;
+    int s = 0;
+    for (int ti = 0; ti < ntiles_mine; ++ti) {
+        f32x4 acc[MREP][NREP];
+#pragma unroll
+        for (int m = 0; m < MREP; ++m)
+#pragma unroll
+            for (int n = 0; n < NREP; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < p.nchunks; ++c, ++s) {
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const int slot = s % D;
+            const char* sx = smem + slot * stage_bytes;
+            const char* sw = smem + wbuf_off + (p.pk_wstat ? c : slot) * WCH + wn * (NREP * 1024) + lane * 16;
+            vec w[NREP];
+#pragma unroll
+            for (int n = 0; n < NREP; ++n) w[n] = *(const vec*)(sw + n * 1024);
+            vec x[MREP];
+#pragma unroll
+            for (int m = 0; m < MREP; ++m) x[m] = *(const vec*)(sx + xa[m]);
+#pragma unroll
+            for (int m = 0; m < MREP; ++m)
+#pragma unroll
+                for (int n = 0; n < NREP; ++n) acc[m][n] = mma(w[n], x[m], acc[m][n]);
+        }
+        const int pix0 = (t + ti * tstride) * tile_px + wm * 80;
+        if (fast_epi) {
+            const char* sb = smem + bias_off + (wn * NREP * 16 + (lane >> 4) * 4 * NREP) * 4;
+            f32x4 bias_r[NREP];
+#pragma unroll
+            for (int n = 0; n < NREP; ++n) bias_r[n] = *(const f32x4*)(sb + n * 16);
+#pragma unroll
+            for (int m = 0; m < MREP; ++m) {
+                const int opix = pix0 + m * 16 + (lane & 15);
+                const bool pv = opix < total_px;
+                const unsigned ob = (unsigned)((opix * p.out_ld + p.out_coff + crun) * ES);
+                f32x4 v[NREP];
+#pragma unroll
+                for (int n = 0; n < NREP; ++n) {
+                    v[n] = acc[m][n] + bias_r[n];
+                    if (p.act) v[n] = silu4<FAST>(v[n]);
+                }
+                if constexpr (sizeof(T) == 2 && NREP % 2 == 0) {
+#pragma unroll
+                    for (int n = 0; n < NREP; n += 2) {
+                        half8 hv;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { hv[j] = (half_t)v[n][j]; hv[4 + j] = (half_t)v[n + 1][j]; }
+                        const bool cv = pv && crun + 4 * n + 8 <= p.Cout;
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hv), rsO, cv ? ob + n * 8 : OOB, 0u, 0);
+                    }
+                } else if constexpr (sizeof(T) == 2) {
+                    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+                    for (int n = 0; n < NREP; ++n) {
+                        half4 hv;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) hv[j] = (half_t)v[n][j];
+                        const bool cv = pv && crun + 4 * n < p.Cout;
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hv), rsO, cv ? ob + n * 8 : OOB, 0u, 0);
+                    }
+                } else {
+#pragma unroll
+                    for (int n = 0; n < NREP; ++n) {
+                        const bool cv = pv && crun + 4 * n < p.Cout;
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[n]), rsO, cv ? ob + n * 16 : OOB, 0u, 0);
+                    }
+                }
+            }
+        } else {
+            int opy[MREP], opx[MREP];
+            bool pvalid[MREP];
+            const int hw = p.Hout * p.Wout;
+            int bfr = 0;
+#pragma unroll
+            for (int m = 0; m < MREP; ++m) {
+                const int opix = pix0 + m * 16 + (lane & 15);
+                pvalid[m] = opix < total_px;
+                const int oc = pvalid[m] ? opix : 0;
+                const int bb = oc / hw, r = oc - bb * hw;
+                opy[m] = r / p.Wout; opx[m] = r - opy[m] * p.Wout;
+                // the shared epilogue addresses pixels as (b * Hout + y) * Wout + x with ONE frame index per call:
+                // fold the frame into y (rows of later frames follow the rows of frame 0 in memory)
+                opy[m] += bb * p.Hout;
+            }
+            conv_epilogue<T, NREP>(p, acc, pvalid, opy, opx, bfr, nt0, wn, lane);
+        }
+    }
+}
+
 template <typename T, int NREP, int WN, int NREP2 = 0>
 static hipError_t launch_pk_one(const ConvParams& p, dim3 grid, int threads, size_t lds, hipStream_t st) {
     auto k = conv3_pk<T, NREP, WN, NREP2>;
@@ -352,6 +569,52 @@ static hipError_t launch_pk_t(int nrep, const ConvParams& p, dim3 grid, int thre
 
 bool conv_pk_instantiated(int nrep, int wn) {
     return (wn == 1 && nrep >= 1 && nrep <= 5) || (wn == 2 && nrep >= 1 && nrep <= 4) || (wn == 4 && nrep >= 1 && nrep <= 2);
+}
+
+template <typename T, int NREP, int WN>
+static hipError_t launch_pk1_one(const ConvParams& p, dim3 grid, int threads, size_t lds, hipStream_t st) {
+    auto k = conv1_pk<T, NREP, WN>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(k, grid, dim3(threads), lds, st, p);
+    return hipGetLastError();
+}
+
+bool conv1_pk_instantiated(int nrep, int wn) { return conv_pk_instantiated(nrep, wn); }
+
+bool conv1_pk_fits(int nwm, int WN, int NREP, int nchunks, int depth, int wstat) {
+    const int ncomp = nwm * WN;
+    if (nwm < 1 || ncomp > 4 || depth < 2 || depth > 8) return false;
+    const int npieces = nwm * 5;
+    if ((npieces + ncomp - 1) / ncomp > PK1_MAXP) return false;
+    const int per_step = (npieces + ncomp - 1) / ncomp + (wstat ? 0 : (WN * NREP + ncomp - 1) / ncomp);
+    if (per_step * (depth - 2) > 63) return false;                     // counted s_waitcnt range
+    return conv1_pk_lds_bytes(nwm, WN, NREP, nchunks, depth, wstat) <= 160 * 1024;
+}
+
+template <typename T>
+static hipError_t launch_pk1_t(int nrep, const ConvParams& p, dim3 grid, int threads, size_t lds, hipStream_t st) {
+#define VTI_L(N, W) if (nrep == N && p.WN == W) return launch_pk1_one<T, N, W>(p, grid, threads, lds, st);
+    VTI_L(1, 1) VTI_L(2, 1) VTI_L(3, 1) VTI_L(4, 1) VTI_L(5, 1) VTI_L(1, 2) VTI_L(2, 2) VTI_L(3, 2) VTI_L(4, 2) VTI_L(1, 4) VTI_L(2, 4)
+#undef VTI_L
+    return hipErrorInvalidValue;
+}
+
+// 1x1: p.TH = compute waves along M, p.TW = 80 (pixels per wave); workgroups as for the 3x3 kernel
+hipError_t launch_conv1_pk(int dtype, int nrep, const ConvParams& p, size_t lds_bytes, hipStream_t st) {
+    const int NTB = p.WN * nrep;
+    if (!conv1_pk_fits(p.TH, p.WN, nrep, p.nchunks, p.pk_depth, p.pk_wstat)) return hipErrorInvalidValue;
+    if (p.ntiles_n % NTB || p.pk_wgs < 1 || (p.pk_xcd && p.pk_wgs % 8) || p.has_res) return hipErrorInvalidValue;
+    if ((size_t)p.in_bytes >= 0x80000000u || (size_t)p.out_bytes >= 0x80000000u) return hipErrorInvalidValue;
+    if (p.pk_tiles == 0) return hipSuccess;
+    const int threads = 2 * p.TH * p.WN * 64;
+    dim3 grid((unsigned)p.pk_wgs, (unsigned)(p.ntiles_n / NTB));
+    if (dtype == VTI_F16) return launch_pk1_t<half_t>(nrep, p, grid, threads, lds_bytes, st);
+    return launch_pk1_t<float>(nrep, p, grid, threads, lds_bytes, st);
 }
 
 // grid.x workgroups (p.pk_wgs, a multiple of 8 when p.pk_xcd) x n-groups; (TH/4) * WN compute + as many loader waves

@@ -146,6 +146,63 @@ static bool choose_pk_cfg(int esize, const ConvRow& r, int max_batch, ConvCfg& c
     return found;
 }
 
+// Geometry for the persistent 1x1 kernel (conv1_pk): tiles of (M-waves x 80) consecutive pixels, a deep stage ring,
+// weights stationary in LDS when all K chunks of the n-group fit in 64 KB.  These layers are HBM-bound: prefer one
+// n-group (the pixels are read once), then the deepest ring, then the fewest rounds.
+static bool choose_pk1_cfg(int esize, const ConvRow& r, int max_batch, ConvCfg& c, int fth, int fwn, int fnrep) {
+    const char* no = getenv("VTI_NO_PK1");
+    if (no && no[0] == '1') return false;
+    const bool deconv = r.kind == 2;
+    if (!((r.k == 1 && r.s == 1) || deconv)) return false;
+    // measured (tools/pk1_sweep.py, bs=64): 15-27 % faster than the per-tile kernel on the 160/80/40-wide maps, slower on the
+    // 20 x 20 maps (a tile's worth of pixels per CU: nothing to pipeline) and on the ConvTranspose scatter epilogue
+    const bool forced = fth || fwn || fnrep;
+    const char* all1 = getenv("VTI_PK1_ALL");
+    if (!forced && !(all1 && all1[0] == '1') && (deconv || r.h_out * r.w_out < 1600)) return false;
+    const long total_px = (long)max_batch * (deconv ? r.h_in * r.w_in : r.h_out * r.w_out);
+    double best = 1e30;
+    bool found = false;
+    for (int WN = 1; WN <= 4; WN *= 2) {
+        if (fwn && WN != fwn) continue;
+        for (int NREP = 1; NREP <= 5; ++NREP) {
+            if (fnrep && NREP != fnrep) continue;
+            if (!conv_pk_instantiated(NREP, WN)) continue;
+            if (deconv && r.c2 % (16 * NREP)) continue;      // a lane's channel run must stay inside one (dy,dx) plane
+            const int NTB = WN * NREP;
+            const int gy = (c.ntiles_n + NTB - 1) / NTB;
+            const double n_eff = (double)c.ntiles_n / (gy * NTB);
+            if (n_eff < 0.74 && !fnrep) continue;
+            for (int nwm = 1; nwm <= 4; ++nwm) {
+                if (fth && nwm != fth) continue;
+                const int ncomp = nwm * WN;
+                if (ncomp > 4) continue;
+                const int wstat = (size_t)c.nchunks * NTB * 1024 <= 64 * 1024 ? 1 : 0;
+                int depth = 0;
+                for (int dd = 8; dd >= 2; --dd) if (conv1_pk_fits(nwm, WN, NREP, c.nchunks, dd, wstat)) { depth = dd; break; }
+                if (!depth) continue;
+                const long NT = (total_px + nwm * 80 - 1) / (nwm * 80);
+                long G = std::min<long>(NT, std::max(1, 256 / gy));
+                if (G >= 8) G &= ~7L;
+                const long rounds = (NT + G - 1) / G;
+                const double step_cyc = 5.0 * NREP * 16 + 250;
+                const double t_comp = rounds * (c.nchunks * step_cyc + 1100.0 * NREP) * ((ncomp + 3) / 4) / 1.9e9;
+                const double bytes = (double)total_px * ((double)gy * r.c1 + (double)c.gemm_n) * esize +
+                                     (wstat ? 0.0 : (double)NT * gy * c.nchunks * NTB * 1024 * 0.25);   // streamed weights (L2)
+                const double inflight = (double)(depth - 1) * nwm * 80 * 64;                       // bytes in flight per CU
+                const double t_mem = bytes / (5.0e12 * std::min(1.0, inflight / 100e3));
+                const double cost = std::max(t_comp, t_mem) + 0.15 * std::min(t_comp, t_mem) + 4e-6;
+                if (cost < best) {
+                    best = cost; found = true;
+                    c.TH = nwm; c.TW = 80; c.WN = WN; c.NREP = NREP; c.pk = 2; c.pk_wgpc = 1; c.pk_depth = depth; c.pk_wstat = wstat;
+                    c.lds = conv1_pk_lds_bytes(nwm, WN, NREP, c.nchunks, depth, wstat);
+                }
+            }
+        }
+    }
+    if (found) c.ntiles_n = (c.ntiles_n + c.WN * c.NREP - 1) / (c.WN * c.NREP) * (c.WN * c.NREP);
+    return found;
+}
+
 void choose_conv_cfg(int dtype, const ConvRow& r, bool conv0, int max_batch, ConvCfg& c, int fth, int ftw, int fwn,
                      int fnrep, bool allow_pk) {
     const bool f16 = dtype == VTI_F16;
@@ -155,6 +212,7 @@ void choose_conv_cfg(int dtype, const ConvRow& r, bool conv0, int max_batch, Con
     c.ntiles_n = (c.gemm_n + 15) / 16;      // rounded up to whole NREP groups once NREP is chosen (below)
     c.nchunks = conv0 ? (32 / KC) : (r.c1 + KC - 1) / KC;
     c.pk = 0;
+    if (allow_pk && !conv0 && (!ftw || ftw == 80) && (!fth || fth <= 4) && choose_pk1_cfg(f16 ? 2 : 4, r, max_batch, c, fth, fwn, fnrep)) return;
     if (allow_pk && !conv0 && (!ftw || ftw == 20) && (!fth || fth % 4 == 0) && choose_pk_cfg(f16 ? 2 : 4, r, max_batch, c, fth, fwn, fnrep)) return;
     const int ks = deconv ? 1 : r.k, st = deconv ? 1 : r.s;
     const int Ho = deconv ? r.h_in : r.h_out, Wo = deconv ? r.w_in : r.w_out;

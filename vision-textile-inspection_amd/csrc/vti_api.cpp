@@ -89,7 +89,7 @@ int32_t vti_conv_at(const vti_ctx* c, int32_t i, vti_conv_info* o) {
         if (op.kind != OP_CONV && op.kind != OP_CONV0) continue;
         if (op.conv == i) {
             o->tile_h = op.cfg.TH; o->tile_w = op.cfg.TW; o->waves_n = op.cfg.WN; o->nrep = op.cfg.NREP;
-            o->lds_bytes = (int32_t)op.cfg.lds; o->persistent = op.cfg.pk;
+            o->lds_bytes = (int32_t)op.cfg.lds; o->persistent = op.cfg.pk;   // 1: conv3_pk, 2: conv1_pk
         } else if (op.fused == i) {     // runs inside its producer's kernel, on that kernel's geometry
             o->tile_h = op.cfg.TH; o->tile_w = op.cfg.TW; o->waves_n = 1; o->nrep = op.cfg.ntiles2;
             o->lds_bytes = 0; o->fused = 1;
@@ -213,7 +213,22 @@ static void fill_conv_params(int conv_elem_size, ConvParams& p, const ConvRow& r
     p.rw_magic = (unsigned)((0x100000000ull + RWD - 1) / RWD);
     p.tw_magic = (unsigned)((0x100000000ull + (unsigned)g.TW - 1) / (unsigned)g.TW);
     p.wpk_bytes = (unsigned)packed_conv_bytes(r, conv0, g);
-    if (g.pk) {   // persistent kernel: workgroups along x walk the B * tiles_y * tiles_x tiles
+    if (g.pk == 2) {  // persistent 1x1 kernel: tiles are runs of TH * 80 pixels of the flattened [B*H*W] index space
+        const size_t es = conv_elem_size;
+        const size_t npx = (size_t)B * p.Hout * p.Wout;
+        const size_t ib = npx * in_ld * es;
+        const size_t ob = (deconv ? 4 * npx : npx) * out_ld * (out_f32 ? 4 : es);
+        p.pk = (ib < 0x80000000ull && ob < 0x80000000ull && !res) ? 2 : 0;
+        p.in_bytes = (unsigned)ib; p.out_bytes = (unsigned)ob; p.res_bytes = 0;
+        p.pk_depth = g.pk_depth; p.pk_wstat = g.pk_wstat;
+        p.pk_tiles = (int)((npx + (size_t)g.TH * 80 - 1) / ((size_t)g.TH * 80));
+        const int gy = g.ntiles_n / (g.WN * g.NREP);
+        int G = std::min(p.pk_tiles, std::max(1, 256 * g.pk_wgpc / gy));
+        if (const char* cap = getenv("VTI_PK_MAX_WGS")) G = std::max(1, std::min(G, atoi(cap)));
+        p.pk_xcd = G >= 8 ? 1 : 0;
+        if (p.pk_xcd) G &= ~7;
+        p.pk_wgs = G;
+    } else if (g.pk) {   // persistent kernel: workgroups along x walk the B * tiles_y * tiles_x tiles
         const size_t es = conv_elem_size;
         const size_t ib = (size_t)B * r.h_in * r.w_in * in_ld * es, ob = (size_t)B * p.Hout * p.Wout * out_ld * (out_f32 ? 4 : es);
         const size_t rb = res ? (size_t)B * p.Hout * p.Wout * res_ld * es : 0;

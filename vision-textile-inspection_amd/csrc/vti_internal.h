@@ -53,7 +53,8 @@ struct ConvCfg {         // launch geometry chosen at plan time
     int ntiles2 = 0, gemm_n2 = 0;
     size_t wpk_off2 = 0, bias_off2 = 0;
     // persistent LDS-DMA kernel (conv_pk.hip): TW = 20, TH = 4 * M-waves; wgpc = co-resident workgroups per CU
-    int pk = 0, pk_wgpc = 1;
+    int pk = 0, pk_wgpc = 1;         // pk: 1 = conv3_pk, 2 = conv1_pk (TH = compute waves along M, TW = 80)
+    int pk_depth = 2, pk_wstat = 0;  // conv1_pk: stage-ring depth, weights stationary in LDS
 };
 
 struct Op {
@@ -108,7 +109,7 @@ struct ConvParams {
     // stage-2 output scattered straight into pred [B, no, A] (class scores with sigmoid / mask coefficients)
     float* pred; int pred_mode /*0 off, 1 raw, 2 sigmoid*/, pred_no, pred_A, pred_a0, pred_cbase, pred_t;
     // persistent kernel (conv_pk.hip): tile count, workgroups along x, XCD-contiguous tile ranges, tensor sizes
-    int pk, pk_tiles, pk_wgs, pk_xcd;
+    int pk, pk_tiles, pk_wgs, pk_xcd, pk_depth, pk_wstat;
     unsigned in_bytes, out_bytes, res_bytes;
     unsigned long long* stamps;          // diagnostic build only (VTI_STAMPS): 16 s_memtime slots per workgroup
 };
@@ -124,6 +125,9 @@ hipError_t launch_conv_pk(int dtype, int nrep, const ConvParams& p, size_t lds_b
 size_t conv_pk_lds_bytes(int TH, int WN, int NREP, int nchunks);
 bool conv_pk_fits(int TH, int WN, int NREP, int nchunks);
 bool conv_pk_instantiated(int nrep, int wn);
+hipError_t launch_conv1_pk(int dtype, int nrep, const ConvParams& p, size_t lds_bytes, hipStream_t st);
+size_t conv1_pk_lds_bytes(int nwm, int WN, int NREP, int nchunks, int depth, int wstat);
+bool conv1_pk_fits(int nwm, int WN, int NREP, int nchunks, int depth, int wstat);
 
 struct PoolParams { const void* in; void* out; int B, H, W, C, ld, in_coff, out_coff; };
 hipError_t launch_sppf_pool(int dtype, const PoolParams& p, hipStream_t st);
