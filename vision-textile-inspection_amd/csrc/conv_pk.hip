@@ -396,20 +396,44 @@ __global__ __launch_bounds__(512) void conv1_pk(const ConvParams p) {
         const int ppl = (npieces + nld - 1) / nld;                      // pixel pieces per loader and step (<= PK1_MAXP)
         const int wpl = p.pk_wstat ? 0 : (NTB + nld - 1) / nld;         // weight pieces per loader and step
         const int per_step = ppl + wpl;
+        const __amdgpu_buffer_rsrc_t rsA2 = __builtin_amdgcn_make_buffer_rsrc((void*)p.in2, 0, (int)p.in2_bytes, 0x00020000);
+        // per-lane source offsets of this loader's pieces, recomputed when the chain moves to the next tile: vo1 = the conv's
+        // own input; vo2 = the low-resolution source of the folded Upsample (pixel (y >> 1, x >> 1) of the same frame)
+        unsigned vo1[PK1_MAXP], vo2[PK1_MAXP];
+        int cur_ti = -1;
         auto issue = [&](int s) {                                       // DMA of step s of this workgroup's chain
             const int ti = s / p.nchunks, c = s - ti * p.nchunks;
-            const int pix0 = (t + ti * tstride) * tile_px;
+            if (ti != cur_ti) {
+                cur_ti = ti;
+                const int pix0 = (t + ti * tstride) * tile_px;
+                const int hw = p.Hout * p.Wout;
+#pragma unroll
+                for (int u = 0; u < PK1_MAXP; ++u) {
+                    const int piece = lw + u * nld;
+                    const int px = pix0 + piece * 16 + (lane >> 2);
+                    const bool ok = piece < npieces && px < total_px;
+                    vo1[u] = ok ? (unsigned)((px * p.in_ld + p.in_coff + q * VEC) * ES) : OOB;
+                    vo2[u] = OOB;
+                    if (p.up_C > 0 && ok) {
+                        const int bb = px / hw, r = px - bb * hw;
+                        const int y = r / p.Wout, x = r - y * p.Wout;
+                        const int px2 = (bb * (p.Hout >> 1) + (y >> 1)) * (p.Wout >> 1) + (x >> 1);
+                        vo2[u] = (unsigned)((px2 * p.in2_ld + p.in2_coff + q * VEC) * ES);
+                    }
+                }
+            }
             const int slot = s % D;
             const bool qok = c < cvalid;
+            const bool from_up = c * KC < p.up_C;                      // chunk granularity: up_C is a multiple of KC
             const unsigned dst = lds0 + slot * stage_bytes;
 #pragma unroll
             for (int u = 0; u < PK1_MAXP; ++u) {
                 if (u >= ppl) break;
                 const int piece = lw + u * nld;
-                const int px = pix0 + piece * 16 + (lane >> 2);
-                const bool ok = piece < npieces && px < total_px && qok;
-                const unsigned vo = ok ? (unsigned)((px * p.in_ld + p.in_coff + q * VEC) * ES) : OOB;
-                dma16(rsA, vo, (unsigned)(c * KC * ES), piece < npieces ? dst + piece * 1024 : lds0 + dummy_off);
+                const unsigned vo = qok ? (from_up ? vo2[u] : vo1[u]) : OOB;
+                const unsigned ld = piece < npieces ? dst + piece * 1024 : lds0 + dummy_off;
+                if (from_up) dma16(rsA2, vo, (unsigned)(c * KC * ES), ld);
+                else dma16(rsA, vo, (unsigned)(c * KC * ES), ld);
             }
             if (wpl) {
                 const unsigned src = (unsigned)(((size_t)c * p.ntiles_n + nt0) * 1024);

@@ -485,6 +485,34 @@ std::string Plan::build(const vti_desc& d) {
         }
     }
     wpk_bytes = woff; bias_floats = boff;
+
+    // Fold "nearest-2x Upsample -> Concat -> 1x1 conv" (neck layers 10-12, 13-15): when the consumer runs on conv1_pk its
+    // loader reads the upsampled channels straight from the low-resolution tensor at (y >> 1, x >> 1); the UP2 op
+    // and its write + re-read of a 4x larger tensor disappear.
+    {
+        const char* nu = getenv("VTI_NO_UPFUSE");
+        const int KC = d.dtype == VTI_F16 ? 32 : 16;
+        for (size_t i = 0; !(nu && nu[0] == '1') && i < ops.size(); ++i) {
+            if (ops[i].kind != OP_UP2) continue;
+            const View uo = ops[i].out;
+            int consumer = -1, readers = 0;
+            for (size_t j = 0; j < ops.size(); ++j) {
+                if (j == i) continue;
+                const Op& o = ops[j];
+                auto overlaps = [&](const View& v) { return v.buf == uo.buf && v.coff < uo.coff + uo.C && uo.coff < v.coff + v.C; };
+                if ((o.kind == OP_CONV || o.kind == OP_UP2 || o.kind == OP_POOL) && (overlaps(o.in) || (o.has_res && overlaps(o.res)))) {
+                    ++readers; consumer = (int)j;
+                }
+            }
+            if (readers != 1 || consumer < (int)i) continue;
+            Op& cv = ops[consumer];
+            const ConvRow& r = convs[cv.conv];
+            if (cv.kind != OP_CONV || cv.cfg.pk != 2 || r.k != 1 || cv.in.coff != uo.coff || uo.C % KC || uo.C >= cv.in.C || cv.lane != ops[i].lane) continue;
+            cv.up_src = ops[i].in; cv.up_C = uo.C;
+            ops.erase(ops.begin() + i);
+            --i;
+        }
+    }
     return "";
 }
 

@@ -292,6 +292,12 @@ int32_t vti_forward(vti_ctx* c, const uint8_t* input, int32_t B, int32_t swap_rb
                     p.pred_A = P.num_anchors; p.pred_a0 = op.pred_a0; p.pred_cbase = op.pred_cbase; p.pred_t = op.pred_t;
                 }
             }
+            if (op.up_C > 0) {
+                const Buf& ub = P.bufs[op.up_src.buf];
+                p.in2 = buf_ptr(c, op.up_src.buf, input, proto); p.in2_ld = ub.C; p.in2_coff = op.up_src.coff; p.up_C = op.up_C;
+                p.in2_bytes = (unsigned)((size_t)B * ub.H * ub.W * ub.C * P.esize);
+                if (p.pk != 2) return fail(c, VTI_ERR_UNSUPPORTED, "folded upsample needs the persistent 1x1 kernel (tensor too large?)");
+            }
             const bool deconv = r.kind == 2;
             const int ks = deconv ? 1 : r.k, s = deconv ? 1 : r.s;
             VTI_HIP(c, launch_conv(dt, ks, s, g.NREP, op.kind == OP_CONV0 ? 1 : 0, p, g.lds, st), r.name.c_str());

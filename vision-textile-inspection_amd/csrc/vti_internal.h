@@ -68,6 +68,7 @@ struct Op {
     int pred_t = 0;          // ... with pixels as MFMA rows: a lane owns 4 consecutive ANCHORS of one channel (16-byte stores)
     View out2;           // where the fused conv writes
     bool out2_f32 = false;
+    View up_src; int up_C = 0;   // conv1_pk only: channels [0, up_C) of `in` are read as the nearest-2x upsample of up_src (no UP2 op)
     int lane = 0;        // stream the op is enqueued on (OP_FORK/OP_JOIN: the side lane that starts/finishes)
     ConvCfg cfg;
 };
@@ -111,6 +112,8 @@ struct ConvParams {
     // persistent kernel (conv_pk.hip): tile count, workgroups along x, XCD-contiguous tile ranges, tensor sizes
     int pk, pk_tiles, pk_wgs, pk_xcd, pk_depth, pk_wstat;
     unsigned in_bytes, out_bytes, res_bytes;
+    // conv1_pk: channels [0, up_C) come from in2 [B, Hout/2, Wout/2, in2_ld] at (y >> 1, x >> 1): the neck's Upsample + Concat folded into the loads
+    const void* in2; int in2_ld, in2_coff, up_C; unsigned in2_bytes;
     unsigned long long* stamps;          // diagnostic build only (VTI_STAMPS): 16 s_memtime slots per workgroup
 };
 
