@@ -25,7 +25,10 @@
  *  - Tensor layouts (T = fp16 or fp32 per vti_desc.dtype):
  *      frames   u8  [B,H0,W0,3]           camera frames, any channel order (see swap_rb)
  *      input    u8  [B,H,W,3]             letterboxed frames (H,W multiples of 32)
- *      pred     f32 [B,4+nc+nm,A]         decoded head output, Ultralytics layout
+ *      pred     f32 [B,A,4+nc+nm]         decoded head output, ANCHOR-MAJOR: Ultralytics' [B,4+nc+nm,A] transposed, so that
+ *                                         an anchor's box, class scores and mask coefficients are one contiguous row (the head
+ *                                         towers write it and NMS reads it row-wise; the Python shim hands out the
+ *                                         [B,4+nc+nm,A] view of the same memory)
  *                                          (cx,cy,w,h in letterboxed px; sigmoid class scores; coeffs)
  *      proto    T   [B,H/4,W/4,nm]        mask prototypes, NHWC
  *      dets     f32 [B,max_det,6+nm]      rows x1,y1,x2,y2,conf,cls,coeff[nm]; conf-descending;

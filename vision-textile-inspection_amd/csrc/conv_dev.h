@@ -258,73 +258,6 @@ __device__ __forceinline__ void conv_stage2(const ConvParams& p, f32x4 (&acc)[MR
     f32x4 bias1[NREP];
 #pragma unroll
     for (int n = 0; n < NREP; ++n) bias1[n] = *(const f32x4*)(p.bias + (lane >> 4) * 4 * NREP + 4 * n);
-    if (p.pred_t) {
-        // ---- transposed pred stage: the activated register tile is the MFMA ROW operand and the 1x1 weights the
-        // column operand, so accumulator lane (g = lane >> 4, j = lane & 15) holds pixels 4g..4g+3 of its m-tile for
-        // channel 16n + j.  Those four pixels are consecutive anchors of one row (tile width and map width are
-        // multiples of 4), i.e. ONE 16-byte store into pred [B, no, A] instead of four scattered dwords.
-        f32x4 acc2[MREP][NREP2];
-#pragma unroll
-        for (int m = 0; m < MREP; ++m)
-#pragma unroll
-            for (int n = 0; n < NREP2; ++n) acc2[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int t2 = 0; t2 < KT; ++t2) {
-            vec w2[NREP2];
-#pragma unroll
-            for (int n = 0; n < NREP2; ++n)
-                w2[n] = buf_load16<vec>(rsW2, (unsigned)(((t2 * p.ntiles2 + n) * 64 + lane) * 16), 0u);
-#pragma unroll
-            for (int m = 0; m < MREP; ++m) {
-                vec x;
-                if constexpr (sizeof(T) == 2) {
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const int n1 = 2 * t2 + h;
-                        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                        if (n1 < NREP) {
-                            v = acc[m][n1 < NREP ? n1 : 0] + bias1[n1 < NREP ? n1 : 0];
-                            if (p.act) v = silu4<FAST>(v);
-                        }
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) x[h * 4 + j] = (T)v[j];
-                    }
-                } else {
-                    f32x4 v = acc[m][t2] + bias1[t2];
-                    if (p.act) v = silu4<FAST>(v);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) x[j] = v[j];
-                }
-#pragma unroll
-                for (int n = 0; n < NREP2; ++n) acc2[m][n] = mma(x, w2[n], acc2[m][n]);
-            }
-        }
-        float b2[NREP2];
-#pragma unroll
-        for (int n = 0; n < NREP2; ++n) b2[n] = p.bias2[n * 16 + (lane & 15)];
-        const int src = (lane & 48) | ((lane >> 4) * 4);        // the lane of this 16-group that owns pixel 4g of the m-tile
-#pragma unroll
-        for (int m = 0; m < MREP; ++m) {
-            const int y4 = __shfl(opy[m], src), x4 = __shfl(opx[m], src);
-            const bool ok4 = __shfl((int)pvalid[m], src) != 0;
-            if (!ok4) continue;
-            float* o = p.pred + ((size_t)b * p.pred_no + p.pred_cbase + (lane & 15)) * p.pred_A + p.pred_a0 + y4 * p.Wout + x4;
-#pragma unroll
-            for (int n = 0; n < NREP2; ++n) {
-                if (n * 16 + (lane & 15) >= p.Cout2) continue;
-                f32x4 v = acc2[m][n] + (f32x4){b2[n], b2[n], b2[n], b2[n]};
-                if (p.pred_mode == 2) {         // sigmoid: exact in the fp32 parity engine, hw-rate (~1 ulp f32) in fp16
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        if constexpr (FAST) v[j] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v[j] * -1.4426950408889634f));
-                        else v[j] = 1.0f / (1.0f + expf(-v[j]));
-                    }
-                }
-                *(f32x4*)(o + (size_t)n * 16 * p.pred_A) = v;
-            }
-        }
-        return;
-    }
     f32x4 acc2[MREP][NREP2];
 #pragma unroll
     for (int m = 0; m < MREP; ++m)
@@ -361,46 +294,34 @@ __device__ __forceinline__ void conv_stage2(const ConvParams& p, f32x4 (&acc)[MR
             for (int n = 0; n < NREP2; ++n) acc2[m][n] = mma(w2[n], x, acc2[m][n]);
         }
     }
-    // second-stage epilogue: bias2 (+SiLU for proto.cv3), T or fp32 output
+    [[maybe_unused]] const int tid = threadIdx.x;
+    VTI_STAMP(13);
+    // second-stage epilogue: bias2 (+SiLU for proto.cv3 / sigmoid for class scores), T or fp32 output
     f32x4 bias2[NREP2];
-    const int crun2 = (lane >> 4) * 4 * NREP2;      // this lane's consecutive output-channel run
+    // channel of (tile n, element j): permuted rows give the lane a consecutive run of 4*NREP2 channels (16-byte fp16 pairs);
+    // natural rows (nat2, fp32 outputs) give lane group g channels 16n + 4g + j
+    const int crun2 = p.nat2 ? (lane >> 4) * 4 : (lane >> 4) * 4 * NREP2;
+    const int cstep2 = p.nat2 ? 16 : 4;
 #pragma unroll
-    for (int n = 0; n < NREP2; ++n) bias2[n] = *(const f32x4*)(p.bias2 + crun2 + 4 * n);
-    if (p.pred_mode) {
-        // class scores (exact sigmoid: they are compared with `conf`) / mask coefficients go straight
-        // into pred [B, no, A]: channel-major, so 16 lanes (= 16 anchors) of a tile share a 64-B segment
-#pragma unroll
-        for (int m = 0; m < MREP; ++m) {
-            if (!pvalid[m]) continue;
-            float* o = p.pred + ((size_t)b * p.pred_no + p.pred_cbase) * p.pred_A + p.pred_a0 + opy[m] * p.Wout + opx[m];
-#pragma unroll
-            for (int n = 0; n < NREP2; ++n) {
-                const f32x4 v = acc2[m][n] + bias2[n];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int ch = crun2 + 4 * n + j;
-                    if (ch < p.Cout2) {
-                        float r = v[j];
-                        if (p.pred_mode == 2) {     // sigmoid: exact in the fp32 parity engine, hw-rate (~1 ulp f32) in fp16
-                            if constexpr (FAST) r = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(r * -1.4426950408889634f));
-                            else r = 1.0f / (1.0f + expf(-r));
-                        }
-                        o[(size_t)ch * p.pred_A] = r;
-                    }
-                }
-            }
-        }
-    } else
+    for (int n = 0; n < NREP2; ++n) bias2[n] = *(const f32x4*)(p.bias2 + crun2 + cstep2 * n);
 #pragma unroll
     for (int m = 0; m < MREP; ++m) {
         if (!pvalid[m]) continue;
-        const size_t o0 = (((size_t)(b * p.Hout + opy[m])) * p.Wout + opx[m]) * p.out2_ld + p.out2_coff;
+        // out2_bstride = pixels per frame of the destination: Hout*Wout, or the anchor count when the towers write into pred
+        const size_t o0 = ((size_t)b * p.out2_bstride + (size_t)opy[m] * p.Wout + opx[m]) * p.out2_ld + p.out2_coff;
 #pragma unroll
         for (int n = 0; n < NREP2; ++n) {
-            const int cout0 = crun2 + 4 * n;
+            const int cout0 = crun2 + cstep2 * n;
             if (cout0 >= p.Cout2) continue;
             f32x4 v = acc2[m][n] + bias2[n];
-            if (p.act2) v = silu4<FAST>(v);
+            if (p.act2 == 1) v = silu4<FAST>(v);
+            else if (p.act2 == 2) {         // class scores: sigmoid (exact in the fp32 parity engine, hw-rate ~1 ulp f32 in fp16)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if constexpr (FAST) v[j] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v[j] * -1.4426950408889634f));
+                    else v[j] = 1.0f / (1.0f + expf(-v[j]));
+                }
+            }
             const size_t o = o0 + cout0;
             if (p.scalar_store2) {
 #pragma unroll

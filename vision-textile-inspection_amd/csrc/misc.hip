@@ -155,8 +155,8 @@ hipError_t launch_upsample2x(int dtype, const Up2Params& p, hipStream_t st) {
 //   class scores -> sigmoid; mask coefficients copied.
 // One workgroup per (frame, 64 consecutive anchors of one level).  The anchors' rows of the three
 // head tensors ([anchor][64 | nc | nm], anchor-major) are contiguous, so they are loaded with
-// coalesced dwords into an LDS tile [64][no_in+1]; the channel-major pred [B,4+nc+nm,A] is then
-// written 64 anchors (256 B) at a time -- both sides of the transpose are coalesced.
+// coalesced dwords into an LDS tile [64][no_in+1]; the anchor-major pred [B,A,4+nc+nm] rows are then
+// written as one contiguous run.
 constexpr int DEC_TA = 64;
 
 __global__ __launch_bounds__(256) void decode_kernel(const DecodeParams p, int tiles0, int tiles1, int tiles_per_frame) {
@@ -198,10 +198,10 @@ __global__ __launch_bounds__(256) void decode_kernel(const DecodeParams p, int t
     if (a_ < na) tile[a_ * pitch + side] = dist;     // l,t,r,b overwrite the first 4 box logits
     __syncthreads();
     const int no = 4 + p.nc + p.nm;
-    float* out = p.pred + (size_t)b * no * p.A + p.a0[l] + la0;
+    float* out = p.pred + ((size_t)b * p.A + p.a0[l] + la0) * no;       // anchor-major pred [B, A, no]: rows are contiguous
     const float st = (float)p.stride[l];
     for (int i = tid; i < no * DEC_TA; i += 256) {
-        const int ch = i >> 6, a = i & 63;
+        const int a = i / no, ch = i - a * no;
         if (a >= na) continue;
         const float* r = tile + a * pitch;
         float v;
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void decode_kernel(const DecodeParams p, int t
         } else {
             v = r[nbox + ch - 4];
         }
-        out[(size_t)ch * p.A + a] = v;
+        out[(size_t)a * no + ch] = v;
     }
 }
 
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256) void box_decode_kernel(const DecodeParams p, i
     __syncthreads();
     const int no = 4 + p.nc + p.nm;
     const float st = (float)p.stride[l];
-    const int ch = tid >> 6, a = tid & 63;          // 4 box channels x 64 anchors
+    const int a = tid >> 2, ch = tid & 3;           // 64 anchors x 4 box values: 16 contiguous bytes per anchor
     if (a < na) {
         const float* r = dist4 + a * 4;
         const int la = la0 + a;
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) void box_decode_kernel(const DecodeParams p, i
         const float ax = (float)gx + 0.5f, ay = (float)gy + 0.5f;
         const float x1 = ax - r[0], y1 = ay - r[1], x2 = ax + r[2], y2 = ay + r[3];
         const float v = ch == 0 ? ((x1 + x2) / 2.0f) * st : ch == 1 ? ((y1 + y2) / 2.0f) * st : ch == 2 ? (x2 - x1) * st : (y2 - y1) * st;
-        p.pred[((size_t)b * no + ch) * p.A + p.a0[l] + la] = v;
+        p.pred[((size_t)b * p.A + p.a0[l] + la) * no + ch] = v;
     }
 }
 

@@ -470,7 +470,7 @@ std::string Plan::build(const vti_desc& d) {
         }
         else choose_conv_cfg(d.dtype, r, op.kind == OP_CONV0, d.max_batch, op.cfg);
         if (op.cfg.TH == 0) return "no launch configuration for conv " + r.name;
-        op.pred_t = (op.pred_mode && r.w_out % 4 == 0 && op.cfg.TW % 4 == 0 && !getenv("VTI_NO_PRED_T")) ? 1 : 0;
+        op.nat2 = (op.fused >= 0 && (op.pred_mode || op.out2_f32)) ? 1 : 0;
         op.cfg.wpk_off = woff;
         op.cfg.bias_off = boff;
         woff += packed_conv_bytes(r, op.kind == OP_CONV0, op.cfg);

@@ -129,20 +129,21 @@ __global__ __launch_bounds__(256) void nms_scan_kernel(const float* __restrict__
     const int b = blockIdx.y;
     const int a = blockIdx.x * 256 + threadIdx.x;
     if (a >= A) return;
-    const float* P = pred + (size_t)b * (4 + nc + nm) * A;
-    float best = P[(size_t)4 * A + a];
+    const int no = 4 + nc + nm;
+    const float* P = pred + ((size_t)b * A + a) * no;      // pred is anchor-major: [B, A, 4+nc+nm]
+    float best = P[4];
     int j = 0;
     int c = 1;
     for (; c + 8 <= nc; c += 8) {            // 8 independent loads in flight, then the ordered compares
         float v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = P[(size_t)(4 + c + u) * A + a];
+        for (int u = 0; u < 8; ++u) v[u] = P[4 + c + u];
 #pragma unroll
         for (int u = 0; u < 8; ++u)
             if (v[u] > best) { best = v[u]; j = c + u; }
     }
     for (; c < nc; ++c) {
-        const float v = P[(size_t)(4 + c) * A + a];
+        const float v = P[4 + c];
         if (v > best) { best = v; j = c; }
     }
     if (best > conf) {
@@ -203,7 +204,8 @@ __device__ __forceinline__ void nms_body(const float* __restrict__ P, int A, int
     // 3. boxes in sorted order: xywh -> xyxy, + class offset, areas (all fp32 as torch computes them)
     for (int i = tid; i < n; i += NMS_THREADS) {
         const int a = (int)(keys[i] & 0xffffffffu);
-        const float cx = P[a], cy = P[(size_t)A + a], w = P[(size_t)2 * A + a], h = P[(size_t)3 * A + a];
+        const float* Pa = P + (size_t)a * (4 + nc + nm);
+        const float cx = Pa[0], cy = Pa[1], w = Pa[2], h = Pa[3];
         const float dw = w / 2.0f, dh = h / 2.0f;
         const float off = agnostic ? 0.0f : (float)cls_of[a] * NMS_MAX_WH;
         f32x4 bx;
@@ -299,13 +301,13 @@ __device__ __forceinline__ void nms_body(const float* __restrict__ P, int A, int
         const int k = (int)__umulhi((unsigned)e, row_magic), f = e - k * row;
         const int a = kid[k], j = kcls[k];
         if (f < 4) {
-            const float c_ = P[(size_t)(f & 1) * A + a], s_ = P[(size_t)(2 + (f & 1)) * A + a];   // centre, size of this axis
+            const float c_ = P[(size_t)a * (4 + nc + nm) + (f & 1)], s_ = P[(size_t)a * (4 + nc + nm) + 2 + (f & 1)];   // centre, size of this axis
             const float d_ = s_ / 2.0f;
             return f < 2 ? c_ - d_ : c_ + d_;
         }
-        if (f == 4) return P[(size_t)(4 + j) * A + a];
+        if (f == 4) return P[(size_t)a * (4 + nc + nm) + 4 + j];
         if (f == 5) return (float)j;
-        return P[(size_t)(4 + nc + (f - 6)) * A + a];
+        return P[(size_t)a * (4 + nc + nm) + 4 + nc + (f - 6)];
     };
     const int nel = kept * row, ntot = max_det * row;
     for (int e0 = tid; e0 < nel; e0 += 4 * NMS_THREADS) {      // 4 independent gathers in flight per thread

@@ -46,6 +46,33 @@ static int32_t hip_fail(vti_ctx* c, hipError_t e, const char* what) {
 }
 #define VTI_HIP(c, call, what) do { hipError_t e_ = (call); if (e_ != hipSuccess) return hip_fail((c), e_, (what)); } while (0)
 
+#ifdef VTI_STAMPS
+// diagnostic build: medians of the intervals between the in-kernel s_memtime stamps of one launch, to stderr
+static void report_stamps(const std::vector<unsigned long long>& h, size_t nwg, bool pk) {
+    const char* names[16] = {"start", "c0:top", "c0:A staged", "c0:B staged", "c0:barrier", "c0:mfma done",
+                             "c1:top", "c1:A staged", "c1:B staged", "c1:barrier", "c1:mfma done", "epilogue start", "end", "stage2: mfma done", "stage2: stores issued", ""};
+    const char* pkn[16] = {"start", "c0:before barrier", "c0:after barrier", "c0:sub-tile A done", "c0:sub-tile B done",
+                           "c1:before barrier", "c1:after barrier", "c1:sub-tile A done", "c1:sub-tile B done", "", "", "epilogue start", "end", "", "", ""};
+    if (pk) for (int i = 0; i < 16; ++i) names[i] = pkn[i];
+    fprintf(stderr, "[stamps] %zu workgroups; median cycles since previous stamp (100 MHz s_memtime ticks x clock)\n", nwg);
+    int prev = 0;
+    const int order[14] = {1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 14, 12};     // 13/14: inside the fused stage, before `end`
+    for (int oi = 0; oi < 14; ++oi) {
+        const int i = order[oi];
+        std::vector<long long> d;
+        for (size_t w = 0; w < nwg; ++w) if (h[w * 16 + i] && h[w * 16 + prev]) d.push_back((long long)(h[w * 16 + i] - h[w * 16 + prev]));
+        if (d.empty()) continue;
+        std::sort(d.begin(), d.end());
+        fprintf(stderr, "[stamps] %-16s median %8lld  p10 %8lld  p90 %8lld\n", names[i], d[d.size() / 2], d[d.size() / 10], d[d.size() * 9 / 10]);
+        prev = i;
+    }
+    std::vector<long long> tot;
+    for (size_t w = 0; w < nwg; ++w) tot.push_back((long long)(h[w * 16 + 12] - h[w * 16]));
+    std::sort(tot.begin(), tot.end());
+    fprintf(stderr, "[stamps] whole workgroup   median %8lld\n", tot[tot.size() / 2]);
+}
+#endif
+
 extern "C" {
 
 int32_t vti_create(const vti_desc* desc, vti_ctx** out) {
@@ -287,9 +314,14 @@ int32_t vti_forward(vti_ctx* c, const uint8_t* input, int32_t B, int32_t swap_rb
                 p.Cout2 = g.gemm_n2; p.ntiles2 = g.ntiles2; p.out2_ld = o2.C; p.out2_coff = op.out2.coff;
                 p.act2 = P.convs[op.fused].kind == 0; p.out2_f32 = op.out2_f32 ? 1 : 0;
                 p.scalar_store2 = (g.gemm_n2 % 4 || o2.C % 4 || op.out2.coff % 4) ? 1 : 0;
-                if (op.pred_mode) {
-                    p.pred = pred; p.pred_mode = op.pred_mode; p.pred_no = 4 + P.desc.nc + P.desc.nm;
-                    p.pred_A = P.num_anchors; p.pred_a0 = op.pred_a0; p.pred_cbase = op.pred_cbase; p.pred_t = op.pred_t;
+                p.nat2 = op.nat2;
+                p.out2_bstride = r.h_out * r.w_out;
+                if (op.pred_mode) {     // class / coefficient towers write their rows of the anchor-major pred [B, A, no] directly
+                    const int no = 4 + P.desc.nc + P.desc.nm;
+                    p.out2 = pred + (size_t)op.pred_a0 * no;
+                    p.out2_ld = no; p.out2_coff = op.pred_cbase; p.out2_f32 = 1; p.out2_bstride = P.num_anchors;
+                    p.act2 = op.pred_mode == 2 ? 2 : 0;
+                    p.scalar_store2 = (g.gemm_n2 % 4 || no % 4 || op.pred_cbase % 4) ? 1 : 0;
                 }
             }
             if (op.up_C > 0) {
@@ -300,6 +332,28 @@ int32_t vti_forward(vti_ctx* c, const uint8_t* input, int32_t B, int32_t swap_rb
             }
             const bool deconv = r.kind == 2;
             const int ks = deconv ? 1 : r.k, s = deconv ? 1 : r.s;
+#ifdef VTI_STAMPS
+            if (const char* so = getenv("VTI_STAMP_OP")) {     // diagnostic build: stamp this op of the forward (fused ops included)
+                if (r.name == so) {
+                    const int NTBs = g.WN * g.NREP;
+                    const size_t nwg = (p.pk ? (size_t)p.pk_wgs : (size_t)B * p.tiles_y * p.tiles_x) * ((g.ntiles_n + NTBs - 1) / NTBs);
+                    unsigned long long* d_st = nullptr;
+                    if (hipMalloc((void**)&d_st, nwg * 16 * 8) == hipSuccess) {
+                        (void)hipMemset(d_st, 0, nwg * 16 * 8);
+                        p.stamps = d_st;
+                        (void)launch_conv(dt, ks, s, g.NREP, op.kind == OP_CONV0 ? 1 : 0, p, g.lds, st);
+                        (void)hipStreamSynchronize(st);
+                        std::vector<unsigned long long> h(nwg * 16);
+                        (void)hipMemcpy(h.data(), d_st, nwg * 16 * 8, hipMemcpyDeviceToHost);
+                        (void)hipFree(d_st);
+                        fprintf(stderr, "[stamps] op %s\n", so);
+                        report_stamps(h, nwg, p.pk != 0);
+                        p.stamps = nullptr;
+                        break;
+                    }
+                }
+            }
+#endif
             VTI_HIP(c, launch_conv(dt, ks, s, g.NREP, op.kind == OP_CONV0 ? 1 : 0, p, g.lds, st), r.name.c_str());
             break;
         }
@@ -495,25 +549,7 @@ int32_t vti_debug_conv2d(int32_t dtype, const void* dev_in, int32_t B, int32_t H
                 (void)hipMemcpy(h.data(), d_st, nwg * 16 * 8, hipMemcpyDeviceToHost);
                 p.stamps = nullptr;
                 (void)hipFree(d_st);
-                const char* names[16] = {"start", "c0:top", "c0:A staged", "c0:B staged", "c0:barrier", "c0:mfma done",
-                                         "c1:top", "c1:A staged", "c1:B staged", "c1:barrier", "c1:mfma done", "epilogue start", "end", "", "", ""};
-                const char* pkn[16] = {"start", "c0:before barrier", "c0:after barrier", "c0:sub-tile A done", "c0:sub-tile B done",
-                                       "c1:before barrier", "c1:after barrier", "c1:sub-tile A done", "c1:sub-tile B done", "", "", "epilogue start", "end", "", "", ""};
-                if (p.pk) for (int i = 0; i < 16; ++i) names[i] = pkn[i];
-                fprintf(stderr, "[stamps] %zu workgroups; median cycles since previous stamp (100 MHz s_memtime ticks x clock)\n", nwg);
-                int prev = 0;
-                for (int i = 1; i <= 12; ++i) {
-                    std::vector<long long> d;
-                    for (size_t w = 0; w < nwg; ++w) if (h[w * 16 + i] && h[w * 16 + prev]) d.push_back((long long)(h[w * 16 + i] - h[w * 16 + prev]));
-                    if (d.empty()) continue;
-                    std::sort(d.begin(), d.end());
-                    fprintf(stderr, "[stamps] %-16s median %8lld  p10 %8lld  p90 %8lld\n", names[i], d[d.size() / 2], d[d.size() / 10], d[d.size() * 9 / 10]);
-                    prev = i;
-                }
-                std::vector<long long> tot;
-                for (size_t w = 0; w < nwg; ++w) tot.push_back((long long)(h[w * 16 + 12] - h[w * 16]));
-                std::sort(tot.begin(), tot.end());
-                fprintf(stderr, "[stamps] whole workgroup   median %8lld\n", tot[tot.size() / 2]);
+                report_stamps(h, nwg, p.pk != 0);
             }
         }
 #endif

@@ -65,7 +65,8 @@ struct Op {
     bool out_f32 = false;
     int fused = -1;      // conv index of a 1x1 conv fused into this op's epilogue (its own op is dropped)
     int pred_mode = 0, pred_cbase = 0, pred_a0 = 0;   // fused stage writes into pred instead of a head buffer
-    int pred_t = 0;          // ... with pixels as MFMA rows: a lane owns 4 consecutive ANCHORS of one channel (16-byte stores)
+    int nat2 = 0;            // fused stage with an fp32 NHWC output: natural channel order (lane group g owns channels 16n+4g..+3: one
+                             // store instruction then covers 64 contiguous bytes per pixel instead of four 16-byte pieces 64 B apart)
     View out2;           // where the fused conv writes
     bool out2_f32 = false;
     View up_src; int up_C = 0;   // conv1_pk only: channels [0, up_C) of `in` are read as the nearest-2x upsample of up_src (no UP2 op)
@@ -106,9 +107,7 @@ struct ConvParams {
     unsigned wpk_bytes;                  // bytes of this conv's packed weights (buffer-load range check)
     // fused 1x1 second stage: out2 = act2(W2 . silu(conv + bias) + bias2), never touching HBM in between
     const void* w2; const float* bias2; void* out2;
-    int Cout2, ntiles2, out2_ld, out2_coff, act2, out2_f32, scalar_store2;
-    // stage-2 output scattered straight into pred [B, no, A] (class scores with sigmoid / mask coefficients)
-    float* pred; int pred_mode /*0 off, 1 raw, 2 sigmoid*/, pred_no, pred_A, pred_a0, pred_cbase, pred_t;
+    int Cout2, ntiles2, out2_ld, out2_coff, act2 /*0 none, 1 SiLU, 2 sigmoid*/, out2_f32, scalar_store2, nat2, out2_bstride;
     // persistent kernel (conv_pk.hip): tile count, workgroups along x, XCD-contiguous tile ranges, tensor sizes
     int pk, pk_tiles, pk_wgs, pk_xcd, pk_depth, pk_wstat;
     unsigned in_bytes, out_bytes, res_bytes;

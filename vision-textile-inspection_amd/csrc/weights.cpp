@@ -149,7 +149,7 @@ std::string pack_weights(const Plan& plan, const void* blob, size_t nbytes, std:
         if (host_of[i]) {
             const ConvCfg& hc = host_of[i]->cfg;
             pack_conv_stage2(plan.desc.dtype, r, hc.NREP, w.data(), b.data(), wpk.data() + hc.wpk_off2, bias.data() + hc.bias_off2,
-                             host_of[i]->pred_t != 0);
+                             host_of[i]->nat2 != 0);
             continue;
         }
         const Op& op = *op_of[i];

@@ -113,18 +113,34 @@ class Engine:
         check(self._ctx, lib().vti_letterbox(self._ctx, _ptr(frames), B, H0, W0, _ptr(out), _stream()))
         return out
 
+    def alloc_pred(self, B, device):
+        """pred in Ultralytics' logical shape [B, 4+nc+nm, A] over the library's ANCHOR-MAJOR memory [B, A, 4+nc+nm]
+        (each anchor's box, scores and coefficients are one contiguous row: that is how the head towers and NMS touch it)."""
+        return torch.empty((B, self.num_anchors, self.no), dtype=torch.float32, device=device).transpose(1, 2)
+
+    @staticmethod
+    def _anchor_major(pred):
+        """-> a tensor with pred's values whose memory is [B, A, no] contiguous (no copy for tensors from alloc_pred)."""
+        pa = pred.transpose(1, 2)
+        return pa if pa.is_contiguous() else pa.contiguous()
+
     def forward(self, inp, swap_rb=True, pred=None, proto=None):
-        """inp: u8 [B,H,W,3] letterboxed -> pred f32 [B,4+nc+nm,A], proto T [B,H/4,W/4,nm] (NHWC)."""
+        """inp: u8 [B,H,W,3] letterboxed -> pred f32 [B,4+nc+nm,A] (a view of anchor-major memory, see alloc_pred),
+        proto T [B,H/4,W/4,nm] (NHWC)."""
         self._check_input(inp, (self.H, self.W))
         B = inp.shape[0]
         if pred is None:
-            pred = torch.empty((B, self.no, self.num_anchors), dtype=torch.float32, device=inp.device)
+            pred = self.alloc_pred(B, inp.device)
+        elif not pred.transpose(1, 2).is_contiguous():
+            raise ValueError("pred must come from Engine.alloc_pred / alloc_outputs (anchor-major memory)")
         if proto is None:
             proto = torch.empty((B, self.H // 4, self.W // 4, self.nm), dtype=self.torch_dtype, device=inp.device)
         check(self._ctx, lib().vti_forward(self._ctx, _ptr(inp), B, int(bool(swap_rb)), _ptr(pred), _ptr(proto), _stream()))
         return pred, proto
 
     def nms(self, pred, conf=0.25, iou=0.7, max_det=300, agnostic=False, dets=None, counts=None):
+        """pred: [B, 4+nc+nm, A] (any layout; tensors from forward()/alloc_pred are used in place)."""
+        pred = self._anchor_major(pred)
         B = pred.shape[0]
         if dets is None:
             dets = torch.empty((B, max_det, 6 + self.nm), dtype=torch.float32, device=pred.device)
@@ -162,7 +178,7 @@ class Engine:
         dev = device or self.device
         wb = self.W if packing == "u8" else self.W // 8
         return dict(
-            pred=torch.empty((B, self.no, self.num_anchors), dtype=torch.float32, device=dev),
+            pred=self.alloc_pred(B, dev),
             proto=torch.empty((B, self.H // 4, self.W // 4, self.nm), dtype=self.torch_dtype, device=dev),
             dets=torch.empty((B, max_det, 6 + self.nm), dtype=torch.float32, device=dev),
             counts=torch.empty((B,), dtype=torch.int32, device=dev),
