@@ -47,15 +47,16 @@ def test_layerwise_parity(scale, nc, H, W, B, dtype, tol):
         try:
             got = eng.debug_conv_output(i, B).cpu()
         except vti_amd.VtiError:
-            # class / coefficient towers whose fused 1x1 writes straight into pred: checked via pred below
-            assert t["fused"] and (".cv3." in t["name"] or ".cv4." in t["name"]), t["name"]
+            # class / coefficient towers whose fused 1x1 writes straight into pred, and (fp16 engine) box towers whose fused
+            # 1x1 stage also does DFL + dist2bbox: checked via pred below
+            assert t["fused"] and (".cv3." in t["name"] or ".cv4." in t["name"] or (dtype == "fp16" and ".cv2." in t["name"])), t["name"]
             continue
         checked += 1
         ref = om.taps[t["name"]]
         assert got.shape == ref.shape and torch.isfinite(ref).all(), t["name"]
         err = (got - ref).abs().max().item()
         assert err <= tol * max(ref.abs().max().item(), 1.0), f"{t['name']}: max|d|={err:.3e} ref max={ref.abs().max():.3e}"
-    assert checked >= len(table) - 16
+    assert checked >= len(table) - 19
     assert pred.shape == opred.shape and torch.isfinite(pred).all()
     if scale != "n":
         return      # m/s random nets carry |logit| ~ 100: only the per-layer bound above is meaningful there

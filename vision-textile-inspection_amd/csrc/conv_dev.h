@@ -304,6 +304,44 @@ __device__ __forceinline__ void conv_stage2(const ConvParams& p, f32x4 (&acc)[MR
     const int cstep2 = p.nat2 ? 16 : 4;
 #pragma unroll
     for (int n = 0; n < NREP2; ++n) bias2[n] = *(const f32x4*)(p.bias2 + crun2 + cstep2 * n);
+    if constexpr (NREP2 == 4) {
+        if (p.act2 == 3) {
+            // ---- box tower: DFL + dist2bbox here.  Natural channel order: tile n is side n (l,t,r,b) and lane
+            // group g = lane >> 4 holds bins 4g..4g+3 of this lane's pixel; the softmax over a side's 16 bins is a 4-value
+            // partial per lane plus a butterfly over the 4 lane groups (lanes l, l^16, l^32, l^48).  Lane group g then
+            // stores component g of (cx, cy, w, h) * stride: 4 lanes x 4 B = the first 16 bytes of the anchor's pred row.
+            const int g = lane >> 4;
+#pragma unroll
+            for (int m = 0; m < MREP; ++m) {
+                float d4[4];
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    const f32x4 v = acc2[m][n] + bias2[n];
+                    float mx = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+                    mx = fmaxf(mx, __shfl_xor(mx, 16));
+                    mx = fmaxf(mx, __shfl_xor(mx, 32));
+                    float e[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if constexpr (FAST) e[j] = __builtin_amdgcn_exp2f((v[j] - mx) * 1.4426950408889634f);
+                        else e[j] = expf(v[j] - mx);
+                    }
+                    float s = (e[0] + e[1]) + (e[2] + e[3]);
+                    float w = (e[0] * (float)(4 * g) + e[1] * (float)(4 * g + 1)) + (e[2] * (float)(4 * g + 2) + e[3] * (float)(4 * g + 3));
+                    s += __shfl_xor(s, 16); w += __shfl_xor(w, 16);
+                    s += __shfl_xor(s, 32); w += __shfl_xor(w, 32);
+                    d4[n] = w / s;
+                }
+                const float ax = (float)opx[m] + 0.5f, ay = (float)opy[m] + 0.5f;
+                const float x1 = ax - d4[0], y1 = ay - d4[1], x2 = ax + d4[2], y2 = ay + d4[3];
+                const float comp = g == 0 ? ((x1 + x2) / 2.0f) * p.dfl_stride : g == 1 ? ((y1 + y2) / 2.0f) * p.dfl_stride
+                                 : g == 2 ? (x2 - x1) * p.dfl_stride : (y2 - y1) * p.dfl_stride;
+                if (pvalid[m])
+                    ((float*)p.out2)[((size_t)b * p.out2_bstride + (size_t)opy[m] * p.Wout + opx[m]) * p.out2_ld + p.out2_coff + g] = comp;
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int m = 0; m < MREP; ++m) {
         if (!pvalid[m]) continue;

@@ -454,6 +454,24 @@ std::string Plan::build(const vti_desc& d) {
                 op.pred_a0 = a0[l];
                 conv_out[op.fused].buf = -1;     // lives in pred only
             }
+            // fp16 engine: the box towers' fused 1x1 stage also does the DFL expectation + dist2bbox and writes the 4 box
+            // values of its anchors -- the fp32 logits [B, HW, 64] and the decode kernel disappear.  (The fp32 parity engine keeps
+            // the separate decode: its softmax sums in the reference's order.)
+            const char* nd = getenv("VTI_NO_DFL_FUSE");
+            int nbox = 0;
+            for (Op& op : ops)
+                if (op.kind == OP_CONV && op.fused >= 0 && convs[op.fused].name.rfind("model.22.cv2.", 0) == 0 && convs[op.fused].c2 == 64) ++nbox;
+            dfl_fused = nbox == 3 && d.dtype == VTI_F16 && d.reg_max == 16 && !(nd && nd[0] == '1');
+            if (dfl_fused) {
+                for (Op& op : ops) {
+                    if (op.kind != OP_CONV || op.fused < 0 || convs[op.fused].name.rfind("model.22.cv2.", 0) != 0) continue;
+                    const int l = convs[op.fused].name[13] - '0';
+                    op.pred_mode = 3; op.pred_cbase = 0; op.pred_a0 = a0[l]; op.dfl_stride = levels[l].stride;
+                    conv_out[op.fused].buf = -1;
+                }
+                for (size_t i = 0; i < ops.size(); ++i)
+                    if (ops[i].kind == OP_DECODE) { ops.erase(ops.begin() + i); break; }
+            }
         }
     }
 

@@ -320,7 +320,8 @@ int32_t vti_forward(vti_ctx* c, const uint8_t* input, int32_t B, int32_t swap_rb
                     const int no = 4 + P.desc.nc + P.desc.nm;
                     p.out2 = pred + (size_t)op.pred_a0 * no;
                     p.out2_ld = no; p.out2_coff = op.pred_cbase; p.out2_f32 = 1; p.out2_bstride = P.num_anchors;
-                    p.act2 = op.pred_mode == 2 ? 2 : 0;
+                    p.act2 = op.pred_mode == 2 ? 2 : op.pred_mode == 3 ? 3 : 0;
+                    p.dfl_stride = (float)op.dfl_stride;
                     p.scalar_store2 = (g.gemm_n2 % 4 || no % 4 || op.pred_cbase % 4) ? 1 : 0;
                 }
             }

@@ -64,7 +64,8 @@ struct Op {
     bool has_res = false;
     bool out_f32 = false;
     int fused = -1;      // conv index of a 1x1 conv fused into this op's epilogue (its own op is dropped)
-    int pred_mode = 0, pred_cbase = 0, pred_a0 = 0;   // fused stage writes into pred instead of a head buffer
+    int pred_mode = 0, pred_cbase = 0, pred_a0 = 0;   // fused stage writes into pred instead of a head buffer (1 raw, 2 sigmoid, 3 DFL boxes)
+    int dfl_stride = 0;      // pred_mode 3: the level's stride (box tower: DFL expectation + dist2bbox in the epilogue)
     int nat2 = 0;            // fused stage with an fp32 NHWC output: natural channel order (lane group g owns channels 16n+4g..+3: one
                              // store instruction then covers 64 contiguous bytes per pixel instead of four 16-byte pieces 64 B apart)
     View out2;           // where the fused conv writes
@@ -88,6 +89,7 @@ struct Plan {
     View proto_src;                      // input of proto.cv3 (so cv3 writes straight to the caller's proto)
     int num_anchors = 0;
     bool pred_scatter = false;           // class/coefficient towers write pred directly; decode handles boxes only
+    bool dfl_fused = false;              // ... and the box towers decode their own boxes: no decode op at all
     size_t ws_bytes = 0;
     size_t wpk_bytes = 0, bias_floats = 0;
     int64_t macs = 0, fused_params = 0;
@@ -107,7 +109,8 @@ struct ConvParams {
     unsigned wpk_bytes;                  // bytes of this conv's packed weights (buffer-load range check)
     // fused 1x1 second stage: out2 = act2(W2 . silu(conv + bias) + bias2), never touching HBM in between
     const void* w2; const float* bias2; void* out2;
-    int Cout2, ntiles2, out2_ld, out2_coff, act2 /*0 none, 1 SiLU, 2 sigmoid*/, out2_f32, scalar_store2, nat2, out2_bstride;
+    int Cout2, ntiles2, out2_ld, out2_coff, act2 /*0 none, 1 SiLU, 2 sigmoid, 3 DFL + dist2bbox*/, out2_f32, scalar_store2, nat2, out2_bstride;
+    float dfl_stride;
     // persistent kernel (conv_pk.hip): tile count, workgroups along x, XCD-contiguous tile ranges, tensor sizes
     int pk, pk_tiles, pk_wgs, pk_xcd, pk_depth, pk_wstat;
     unsigned in_bytes, out_bytes, res_bytes;
