@@ -289,6 +289,214 @@ __global__ __launch_bounds__(256) void stem_kernel(const ConvParams p) {
     conv_epilogue<T, NREP>(p, acc, pvalid, opy, opx, b, nt0, 0, lane);
 }
 
+// ---- stem + layer 1 in one kernel (model.0: 3 -> 16, k3 s2; model.1: 16 -> 32, k3 s2; n-scale channel counts).
+// The 320x320x16 tensor between them is the largest activation of the net (210 MB written + read per 64 frames);
+// here it only ever exists as a (2TH+1) x (2TW+1) x 16 tile in LDS.
+//   phase 1  u8 patch (4TH+3) x (4TW+3) x 3 -> LDS (aligned dwords), exact /255 table          [as stem_kernel]
+//   phase 2  stem on the tile's (2TH+1) x (2TW+1) stem pixels (halo recompute ~6 %): per 16-pixel m-tile one K=27->32
+//            MFMA, bias + SiLU, rounded to T, stored pixel-major [pixel][16 ch]; stem pixels outside the stem map are
+//            layer 1's zero padding
+//   phase 3  layer 1 as implicit GEMM straight from that LDS tile: Cin = 16, so one 32-deep fp16 MFMA step covers TWO taps
+//            (lane group g -> tap 2s + (g >> 1), channels 8 (g & 1) ..; fp32: one tap per 16-deep step); 5 (9) steps
+//   phase 4  the shared epilogue (bias, SiLU, NHWC stores) on layer 1's 16 x 20 output tile
+// ConvParams roles: in = u8 frames [B, Hin, Win, 3]; wpk / bias / out / Cout / Hout / Wout describe LAYER 1;
+// w2 / bias2 = the stem's packed weights / bias.
+constexpr int SL_TH = 16, SL_TW = 20;
+constexpr int SL_SH = 2 * SL_TH + 1, SL_SW = 2 * SL_TW + 1, SL_NSP = SL_SH * SL_SW;       // stem pixels per tile
+constexpr int SL_RH = 4 * SL_TH + 3, SL_RWB = (4 * SL_TW + 3) * 3, SL_RWD = (SL_RWB + 6) >> 2, SL_PITCH = SL_RWD * 4;
+
+size_t stem_l1_lds_bytes(int dtype) {
+    const size_t es = dtype == VTI_F16 ? 2 : 4;
+    return (((size_t)SL_RH * SL_PITCH * es + 15) & ~(size_t)15) + (size_t)SL_NSP * 16 * es;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void stem_l1_kernel(const ConvParams p) {
+    using vec = typename Tr<T>::vec;
+    constexpr int VEC = Tr<T>::VEC, KC = Tr<T>::KC, ES = (int)sizeof(T);
+    constexpr int NCH = 32 / KC;                        // stem K chunks (27 -> 32)
+    constexpr int NS1 = sizeof(T) == 2 ? 5 : 9;         // layer-1 K steps
+    constexpr bool FAST = sizeof(T) == 2;
+    constexpr int CP_BYTES = (SL_RH * SL_PITCH * ES + 15) & ~15;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* cp = (T*)smem;                                   // the input patch, already v/255 in T: [row][SL_PITCH]
+    char* sout = smem + CP_BYTES;                       // [stem pixel][16 ch] of T
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
+    int t = blockIdx.x;
+    const int tx = t % p.tiles_x; t /= p.tiles_x;
+    const int ty = t % p.tiles_y;
+    const int b = t / p.tiles_y;
+    const int oy0 = ty * SL_TH, ox0 = tx * SL_TW;       // layer-1 output tile origin
+    const int sy0 = 2 * oy0 - 1, sx0 = 2 * ox0 - 1;     // stem-map origin of the tile's stem pixels
+    const int Hs = (p.Hin - 1) / 2 + 1, Ws = (p.Win - 1) / 2 + 1;       // stem map (k3 s2 p1)
+    const int iy0 = 2 * sy0 - 1;
+    const int x0b = (2 * sx0 - 1) * 3, a0 = x0b & ~3, shift = x0b - a0;
+    const uint8_t* inb = (const uint8_t*)p.in + (size_t)b * p.Hin * p.Win * 3;
+    const int rowbytes = p.Win * 3;
+    VTI_STAMP(0);
+    // ---- phase 1: u8 -> T(v / 255) while staging.  fp16: v * (1/255) rounds to the same half as v / 255 for all 256 byte
+    // values (checked exhaustively), so no table and no division; fp32 divides (what torch's `im.float() / 255` does).
+    {   // wave w stages rows w, w+4, ...; lane = dword of the row: all row arithmetic is scalar, the column test is done once,
+        // and every load of the wave is issued before the first one is consumed
+        constexpr int NIT = (SL_RH + 3) / 4;
+        static_assert(SL_RWD <= 64, "one lane per dword of a patch row");
+        const int gx = a0 + 4 * lane;
+        const bool col_ok = lane < SL_RWD && gx >= 0 && gx < rowbytes;
+        unsigned vv[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int ry = wave + 4 * it;
+            const int y = iy0 + ry;
+            unsigned v = 0;
+            const bool row_ok = ry < SL_RH && (unsigned)y < (unsigned)p.Hin;
+            if ((rowbytes & 3) == 0) {
+                // branch-free: an unconditional load from a clamped address, then a select (a load inside a branch makes the
+                // compiler wait for it at the join, which serialises the 17 round trips)
+                const bool ok = row_ok && col_ok;
+                const unsigned ld = *(const unsigned*)(inb + (ok ? (size_t)y * rowbytes + gx : (size_t)0));
+                v = ok ? ld : 0u;
+            } else if (row_ok && lane < SL_RWD) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (gx + k >= 0 && gx + k < rowbytes) v |= (unsigned)inb[(size_t)y * rowbytes + gx + k] << (8 * k);
+            }
+            vv[it] = v;
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int ry = wave + 4 * it;
+            if (ry >= SL_RH || lane >= SL_RWD) continue;
+            const unsigned v = vv[it];
+            T* o = cp + (size_t)ry * SL_PITCH + 4 * lane;
+            if constexpr (sizeof(T) == 2) {
+                half4 hv;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) hv[k] = (half_t)((float)((v >> (8 * k)) & 0xffu) * (1.0f / 255.0f));
+                *(half4*)o = hv;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o[k] = (float)((v >> (8 * k)) & 0xffu) / 255.0f;
+            }
+        }
+    }
+    __syncthreads();
+    VTI_STAMP(1);
+    // ---- phase 2: stem (two m-tiles per iteration so their LDS gathers overlap)
+    {
+        int off[NCH][VEC];
+        vec w[NCH];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const int k = c * KC + g * VEC + j;
+                const int tap = k / 3, chn = k - tap * 3;
+                const int kh = tap / 3, kw = tap - kh * 3;
+                off[c][j] = k < 27 ? kh * SL_PITCH + kw * 3 + (p.swap_rb ? 2 - chn : chn) : -1;
+            }
+            w[c] = ((const vec*)p.w2)[(size_t)c * 64 + lane];          // one n-tile (16 stem channels)
+        }
+        const f32x4 bias4 = *(const f32x4*)(p.bias2 + g * 4);
+        constexpr int NMT = (SL_NSP + 15) / 16;
+        constexpr int UN = 4;
+        for (int mt0 = wave; mt0 < NMT; mt0 += 4 * UN) {
+            f32x4 acc[UN];
+            int q[UN];
+            bool inside[UN];
+            vec x[UN][NCH];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int mt = mt0 + 4 * u;
+                q[u] = mt * 16 + (lane & 15);
+                const int qc = q[u] < SL_NSP ? q[u] : SL_NSP - 1;
+                const int sy = qc / SL_SW, sx = qc - sy * SL_SW;
+                const int rbase = (2 * sy) * SL_PITCH + (2 * sx) * 3 + shift;
+                inside[u] = (unsigned)(sy0 + sy) < (unsigned)Hs && (unsigned)(sx0 + sx) < (unsigned)Ws;
+#pragma unroll
+                for (int c = 0; c < NCH; ++c)
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) x[u][c][j] = off[c][j] >= 0 ? cp[rbase + off[c][j]] : (T)0;
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                acc[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) acc[u] = mma(w[c], x[u][c], acc[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                f32x4 v = silu4<FAST>(acc[u] + bias4);
+                if (!inside[u]) v = (f32x4){0.f, 0.f, 0.f, 0.f};           // layer 1's zero padding
+                if (q[u] < SL_NSP) {
+                    T* o = (T*)(sout + ((size_t)q[u] * 16 + g * 4) * ES);
+                    if constexpr (sizeof(T) == 2) {
+                        half4 hv;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) hv[j] = (half_t)v[j];
+                        *(half4*)o = hv;
+                    } else {
+                        *(f32x4*)o = v;
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    VTI_STAMP(2);
+    // ---- phase 3: layer 1 from the LDS tile
+    int opy[MREP], opx[MREP], sbase[MREP];
+    bool pvalid[MREP];
+#pragma unroll
+    for (int m = 0; m < MREP; ++m) {
+        const int pp = (wave * MREP + m) * 16 + (lane & 15);           // < 320 = TH * TW
+        const int py = pp / SL_TW, px = pp - py * SL_TW;
+        opy[m] = oy0 + py; opx[m] = ox0 + px;
+        pvalid[m] = opy[m] < p.Hout && opx[m] < p.Wout;
+        sbase[m] = ((2 * py) * SL_SW + 2 * px) * 16 * ES;
+    }
+    f32x4 acc[MREP][2];
+#pragma unroll
+    for (int m = 0; m < MREP; ++m) { acc[m][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[m][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int s = 0; s < NS1; ++s) {
+        const int tap = sizeof(T) == 2 ? 2 * s + (g >> 1) : s;
+        const int tc = tap < 9 ? tap : 8;                               // the 10th half-step multiplies by zero weights
+        const int toff = ((tc / 3) * SL_SW + (tc % 3)) * 16 * ES + (sizeof(T) == 2 ? (g & 1) * 8 : g * 4) * ES;
+        vec w1[2];
+#pragma unroll
+        for (int n = 0; n < 2; ++n) w1[n] = ((const vec*)p.wpk)[((size_t)s * 2 + n) * 64 + lane];
+#pragma unroll
+        for (int m = 0; m < MREP; ++m) {
+            const vec x = *(const vec*)(sout + sbase[m] + toff);
+#pragma unroll
+            for (int n = 0; n < 2; ++n) acc[m][n] = mma(w1[n], x, acc[m][n]);
+        }
+    }
+    VTI_STAMP(3);
+    // ---- phase 4
+    conv_epilogue<T, 2>(p, acc, pvalid, opy, opx, b, 0, 0, lane);
+    VTI_STAMP(12);
+}
+
+hipError_t launch_stem_l1(int dtype, const ConvParams& p, hipStream_t st) {
+    dim3 grid((unsigned)(p.B * p.tiles_y * p.tiles_x));
+    if (grid.x == 0) return hipSuccess;
+    const size_t lds = stem_l1_lds_bytes(dtype);
+    if (dtype == VTI_F16) {
+        hipLaunchKernelGGL(stem_l1_kernel<half_t>, grid, dim3(256), lds, st, p);
+    } else {
+        static bool attr_done = false;
+        if (!attr_done) {
+            hipError_t e = hipFuncSetAttribute((const void*)stem_l1_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+            attr_done = true;
+        }
+        hipLaunchKernelGGL(stem_l1_kernel<float>, grid, dim3(256), lds, st, p);
+    }
+    return hipGetLastError();
+}
+
 size_t stem_lds_bytes(int TH, int TW) { return 1024 + (size_t)(2 * TH + 1) * ((((2 * TW + 1) * 3 + 6) >> 2) * 4); }
 
 // Host-side check that a geometry fits the kernel's fixed register staging arrays.

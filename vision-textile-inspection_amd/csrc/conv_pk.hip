@@ -608,7 +608,7 @@ static hipError_t launch_pk1_one(const ConvParams& p, dim3 grid, int threads, si
     return hipGetLastError();
 }
 
-bool conv1_pk_instantiated(int nrep, int wn) { return conv_pk_instantiated(nrep, wn); }
+bool conv1_pk_instantiated(int nrep, int wn) { return conv_pk_instantiated(nrep, wn) || (wn == 4 && nrep == 4); }
 
 bool conv1_pk_fits(int nwm, int WN, int NREP, int nchunks, int depth, int wstat) {
     const int ncomp = nwm * WN;
@@ -623,7 +623,7 @@ bool conv1_pk_fits(int nwm, int WN, int NREP, int nchunks, int depth, int wstat)
 template <typename T>
 static hipError_t launch_pk1_t(int nrep, const ConvParams& p, dim3 grid, int threads, size_t lds, hipStream_t st) {
 #define VTI_L(N, W) if (nrep == N && p.WN == W) return launch_pk1_one<T, N, W>(p, grid, threads, lds, st);
-    VTI_L(1, 1) VTI_L(2, 1) VTI_L(3, 1) VTI_L(4, 1) VTI_L(5, 1) VTI_L(1, 2) VTI_L(2, 2) VTI_L(3, 2) VTI_L(4, 2) VTI_L(1, 4) VTI_L(2, 4)
+    VTI_L(1, 1) VTI_L(2, 1) VTI_L(3, 1) VTI_L(4, 1) VTI_L(5, 1) VTI_L(1, 2) VTI_L(2, 2) VTI_L(3, 2) VTI_L(4, 2) VTI_L(1, 4) VTI_L(2, 4) VTI_L(4, 4)
 #undef VTI_L
     return hipErrorInvalidValue;
 }

@@ -158,7 +158,8 @@ static bool choose_pk1_cfg(int esize, const ConvRow& r, int max_batch, ConvCfg& 
     // 20 x 20 maps (a tile's worth of pixels per CU: nothing to pipeline) and on the ConvTranspose scatter epilogue
     const bool forced = fth || fwn || fnrep;
     const char* all1 = getenv("VTI_PK1_ALL");
-    if (!forced && !(all1 && all1[0] == '1') && (deconv || r.h_out * r.w_out < 1600)) return false;
+    const char* dc1 = getenv("VTI_PK1_DECONV");
+    if (!forced && !(all1 && all1[0] == '1') && ((deconv && !(dc1 && dc1[0] == '1')) || r.h_out * r.w_out < 1600)) return false;
     const long total_px = (long)max_batch * (deconv ? r.h_in * r.w_in : r.h_out * r.w_out);
     double best = 1e30;
     bool found = false;
@@ -166,7 +167,7 @@ static bool choose_pk1_cfg(int esize, const ConvRow& r, int max_batch, ConvCfg& 
         if (fwn && WN != fwn) continue;
         for (int NREP = 1; NREP <= 5; ++NREP) {
             if (fnrep && NREP != fnrep) continue;
-            if (!conv_pk_instantiated(NREP, WN)) continue;
+            if (!conv1_pk_instantiated(NREP, WN)) continue;
             if (deconv && r.c2 % (16 * NREP)) continue;      // a lane's channel run must stay inside one (dy,dx) plane
             const int NTB = WN * NREP;
             const int gy = (c.ntiles_n + NTB - 1) / NTB;
@@ -429,6 +430,27 @@ std::string Plan::build(const vti_desc& d) {
         }
     }
 
+    // stem + layer 1 in one kernel (n-scale channel counts: 3 -> 16 -> 32): the 320x320x16 tensor stays in LDS
+    {
+        const char* nsf = getenv("VTI_NO_STEM_FUSE");
+        if (!(nsf && nsf[0] == '1') && ops.size() >= 2 && ops[0].kind == OP_CONV0 && ops[1].kind == OP_CONV) {
+            Op& a = ops[0];
+            const Op& b1 = ops[1];
+            const ConvRow& r0 = convs[a.conv];
+            const ConvRow& r1 = convs[b1.conv];
+            bool other_reader = false;
+            for (size_t j = 2; j < ops.size(); ++j)
+                if ((ops[j].kind == OP_CONV || ops[j].kind == OP_UP2 || ops[j].kind == OP_POOL) &&
+                    (ops[j].in.buf == a.out.buf || (ops[j].has_res && ops[j].res.buf == a.out.buf))) other_reader = true;
+            if (r0.c2 == 16 && r0.k == 3 && r0.s == 2 && r1.c1 == 16 && r1.c2 == 32 && r1.k == 3 && r1.s == 2 && r1.kind == 0 &&
+                !b1.has_res && !b1.out_f32 && b1.in.buf == a.out.buf && b1.in.coff == 0 && b1.in.C == 16 && a.lane == b1.lane && !other_reader) {
+                a.fused_l1 = b1.conv; a.out2 = b1.out;
+                conv_out[a.conv].buf = -1;          // the stem's output is never materialised
+                ops.erase(ops.begin() + 1);
+            }
+        }
+    }
+
     // If every class / mask-coefficient tower ends in a fused 1x1, that stage writes its result straight into
     // pred (sigmoid in the epilogue) and the decode kernel only has to turn the box logits into boxes.
     {
@@ -484,8 +506,11 @@ std::string Plan::build(const vti_desc& d) {
         macs += r.macs(); fused_params += r.fused_params();
         if (op.fused >= 0) {   // whole Cout in one wave; the per-tile kernel (2 workgroups per CU) hides the long fused epilogue better
             const char* pf = getenv("VTI_PK_FUSED");
-            choose_conv_cfg(d.dtype, r, false, d.max_batch, op.cfg, 0, 0, 1, r.c2 / 16, pf && pf[0] == '1');
+            const char* pp = getenv("VTI_PK_FUSED_PROTO");
+            choose_conv_cfg(d.dtype, r, false, d.max_batch, op.cfg, 0, 0, 1, r.c2 / 16,
+                            (pf && pf[0] == '1') || (pp && pp[0] == '1' && r.name == "model.22.proto.cv2"));
         }
+        else if (op.fused_l1 >= 0) choose_conv_cfg(d.dtype, r, true, d.max_batch, op.cfg, 0, 0, 1, 1);   // one 16-channel n-tile: stem_l1_kernel's weight indexing
         else choose_conv_cfg(d.dtype, r, op.kind == OP_CONV0, d.max_batch, op.cfg);
         if (op.cfg.TH == 0) return "no launch configuration for conv " + r.name;
         op.nat2 = (op.fused >= 0 && (op.pred_mode || op.out2_f32)) ? 1 : 0;
@@ -493,6 +518,13 @@ std::string Plan::build(const vti_desc& d) {
         op.cfg.bias_off = boff;
         woff += packed_conv_bytes(r, op.kind == OP_CONV0, op.cfg);
         boff += (size_t)op.cfg.ntiles_n * 16;
+        if (op.fused_l1 >= 0) {
+            const ConvRow& r1 = convs[op.fused_l1];
+            macs += r1.macs(); fused_params += r1.fused_params();
+            op.cfg.wpk_off2 = woff; op.cfg.bias_off2 = boff;
+            woff += packed_l1pairs_bytes(d.dtype);
+            boff += 32;
+        }
         if (op.fused >= 0) {
             const ConvRow& r2 = convs[op.fused];
             macs += r2.macs(); fused_params += r2.fused_params();

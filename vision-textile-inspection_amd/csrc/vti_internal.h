@@ -64,6 +64,7 @@ struct Op {
     bool has_res = false;
     bool out_f32 = false;
     int fused = -1;      // conv index of a 1x1 conv fused into this op's epilogue (its own op is dropped)
+    int fused_l1 = -1;   // OP_CONV0 only: conv index of layer 1 computed by the same kernel (stem_l1_kernel); out/out2 = layer 1's view
     int pred_mode = 0, pred_cbase = 0, pred_a0 = 0;   // fused stage writes into pred instead of a head buffer (1 raw, 2 sigmoid, 3 DFL boxes)
     int dfl_stride = 0;      // pred_mode 3: the level's stride (box tower: DFL expectation + dist2bbox in the epilogue)
     int nat2 = 0;            // fused stage with an fp32 NHWC output: natural channel order (lane group g owns channels 16n+4g..+3: one
@@ -125,6 +126,11 @@ hipError_t launch_conv(int dtype, int ks, int stride, int nrep, int mode, const 
 bool conv_fusable(int nrep, int nrep2);   // is there a (3x3 NREP) + (1x1 NREP2) fused instantiation
 size_t conv_lds_bytes(int ks, int stride, int mode, int TH, int TW, int WN, int NREP);
 bool conv_cfg_fits(int ks, int stride, int mode, int TH, int TW, int WN, int NREP);
+// stem (3->16, k3 s2) + layer 1 (16->32, k3 s2) in one kernel: 16 x 20 layer-1 output tiles
+hipError_t launch_stem_l1(int dtype, const ConvParams& p, hipStream_t st);
+size_t stem_l1_lds_bytes(int dtype);
+void pack_conv_l1pairs(int dtype, const ConvRow& r1, const float* w, const float* b, uint8_t* dst_w, float* dst_b);
+size_t packed_l1pairs_bytes(int dtype);
 // conv_pk.hip: persistent 3x3/s1 kernel
 hipError_t launch_conv_pk(int dtype, int nrep, const ConvParams& p, size_t lds_bytes, hipStream_t st);
 size_t conv_pk_lds_bytes(int TH, int WN, int NREP, int nchunks);
@@ -133,6 +139,7 @@ bool conv_pk_instantiated(int nrep, int wn);
 hipError_t launch_conv1_pk(int dtype, int nrep, const ConvParams& p, size_t lds_bytes, hipStream_t st);
 size_t conv1_pk_lds_bytes(int nwm, int WN, int NREP, int nchunks, int depth, int wstat);
 bool conv1_pk_fits(int nwm, int WN, int NREP, int nchunks, int depth, int wstat);
+bool conv1_pk_instantiated(int nrep, int wn);
 
 struct PoolParams { const void* in; void* out; int B, H, W, C, ld, in_coff, out_coff; };
 hipError_t launch_sppf_pool(int dtype, const PoolParams& p, hipStream_t st);

@@ -105,6 +105,29 @@ void pack_conv_stage2(int dtype, const ConvRow& r2, int nrep1, const float* w, c
     for (int n = 0; n < nt2 * 16; ++n) bd[n] = n < r2.c2 ? b[n] : 0.f;
 }
 
+// Layer 1 (16 -> 32, k3 s2) inside stem_l1_kernel: K = 9 taps x 16 channels walked in MFMA steps that pair taps.
+// fp16: step s, lane group g -> tap 2s + (g >> 1), channels 8 (g & 1) + j (j < 8); the 10th half-step is zero.
+// fp32: step s = tap s, channels 4 g + j (j < 4).  Layout [step][ntile 0..1][lane][VEC]; rows permuted as for NREP = 2.
+size_t packed_l1pairs_bytes(int dtype) { return (size_t)(dtype == VTI_F16 ? 5 : 9) * 2 * 1024; }
+
+void pack_conv_l1pairs(int dtype, const ConvRow& r1, const float* w, const float* b, uint8_t* dst, float* bd) {
+    const bool f16 = dtype == VTI_F16;
+    const int NS = f16 ? 5 : 9, VEC = f16 ? 8 : 4;
+    for (int s = 0; s < NS; ++s)
+        for (int nt = 0; nt < 2; ++nt)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < VEC; ++j) {
+                    const int g = lane >> 4, co = perm_cout(nt, lane & 15, 2);
+                    const int tap = f16 ? 2 * s + (g >> 1) : s;
+                    const int ch = f16 ? (g & 1) * 8 + j : g * 4 + j;
+                    const float v = (tap < 9 && co < r1.c2) ? w[((size_t)co * r1.c1 + ch) * 9 + tap] : 0.f;
+                    const size_t e = (((size_t)s * 2 + nt) * 64 + lane) * VEC + j;
+                    if (f16) ((_Float16*)dst)[e] = (_Float16)v;
+                    else ((float*)dst)[e] = v;
+                }
+    for (int n = 0; n < 32; ++n) bd[n] = n < r1.c2 ? b[n] : 0.f;
+}
+
 std::string pack_weights(const Plan& plan, const void* blob, size_t nbytes, std::vector<uint8_t>& wpk,
                          std::vector<float>& bias) {
     const uint8_t* p = (const uint8_t*)blob;
@@ -121,11 +144,12 @@ std::string pack_weights(const Plan& plan, const void* blob, size_t nbytes, std:
     bias.assign(plan.bias_floats, 0.f);
 
     // conv index -> op (cfg); a conv fused into its producer's epilogue maps to that producer
-    std::vector<const Op*> op_of(plan.convs.size(), nullptr), host_of(plan.convs.size(), nullptr);
+    std::vector<const Op*> op_of(plan.convs.size(), nullptr), host_of(plan.convs.size(), nullptr), l1_host(plan.convs.size(), nullptr);
     for (const Op& op : plan.ops)
         if (op.kind == OP_CONV || op.kind == OP_CONV0) {
             op_of[op.conv] = &op;
             if (op.fused >= 0) host_of[op.fused] = &op;
+            if (op.fused_l1 >= 0) l1_host[op.fused_l1] = &op;
         }
 
     size_t off = sizeof(Hdr);
@@ -146,6 +170,11 @@ std::string pack_weights(const Plan& plan, const void* blob, size_t nbytes, std:
         memcpy(w.data(), p + off, 4 * nw); off += 4 * nw;
         memcpy(b.data(), p + off, 4 * (size_t)r.c2); off += 4 * (size_t)r.c2;
 
+        if (l1_host[i]) {      // layer 1 computed inside the stem's kernel
+            const ConvCfg& hc = l1_host[i]->cfg;
+            pack_conv_l1pairs(plan.desc.dtype, r, w.data(), b.data(), wpk.data() + hc.wpk_off2, bias.data() + hc.bias_off2);
+            continue;
+        }
         if (host_of[i]) {
             const ConvCfg& hc = host_of[i]->cfg;
             pack_conv_stage2(plan.desc.dtype, r, hc.NREP, w.data(), b.data(), wpk.data() + hc.wpk_off2, bias.data() + hc.bias_off2,
