@@ -232,7 +232,7 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
     if os.path.exists(tpath) and B == 64 and args.dtype == "fp16":
         fam = json.load(open(tpath))["families"]
-        traffic = sum(v["total_bytes"] for k, v in fam.items() if k.startswith("conv family") or k in ("decode_kernel", "sppf_pool", "upsample2x"))
+        traffic = sum(v["total_bytes"] for k, v in fam.items() if k.startswith("conv family") or k in ("decode_kernel", "sppf_pool", "upsample2x"))    # the forward's kernels
 
     if rank == 0:
         line = {
@@ -250,7 +250,7 @@ def main():
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / MFMA_PEAK_TFLOPS, 5), "traffic": traffic,
                          "traffic_note": "HBM bytes per forward (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes, profiles/r01_hbm_traffic.json); algorithmic unfused activation bytes = 91.6 MB/frame",
-                         "kernel": f"vti conv family: conv3_pk (persistent LDS-DMA 3x3) + conv_kernel + stem_kernel ({eng.num_launches} launches per forward incl. pool/upsample/decode; 76 convs, 10 fused into their producer)",
+                         "kernel": f"vti conv family: conv3_pk / conv1_pk (persistent LDS-DMA 3x3 / 1x1) + conv_kernel (fused towers, stride 2) + stem_l1_kernel ({eng.num_launches} launches per forward incl. the SPPF pool; 76 convs, 11 fused into their producer, decode fused into the box towers)",
                          "flop_per_launch": flops_per_forward, "avg_ms": round(fwd_ms, 4)},
             "stage_ms": {"forward": round(fwd_ms, 4), "nms+masks+scale_boxes": round(post_ms, 4)},
         }

@@ -15,7 +15,7 @@ import csv, glob, collections, json, sys
 tag = sys.argv[1]
 out = "gpurun_out/profiles"
 def fam(n):
-    if "conv_kernel" in n or "stem_kernel" in n or "conv3_pk" in n: return "conv family (conv_kernel + conv3_pk + stem_kernel)"
+    if "conv_kernel" in n or "stem_kernel" in n or "conv3_pk" in n or "conv1_pk" in n or "stem_l1" in n: return "conv family (conv3_pk + conv1_pk + conv_kernel + stem_l1_kernel)"
     for k in ("decode_kernel", "masks_kernel", "nms_kernel", "nms_scan_kernel", "mask_plan_kernel", "mask_offsets_kernel",
               "sppf_pool", "upsample2x", "scale_boxes", "letterbox"):
         if k in n: return k
@@ -26,10 +26,10 @@ agg = collections.defaultdict(list)
 for r in csv.DictReader(open(f)):
     k = fam(r["Kernel_Name"])
     if k: agg[k].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
-nfwd = len(agg["decode_kernel"])            # one decode per forward
+nfwd = len(agg["sppf_pool"])                # one SPPF pool launch per forward
 lines = [f"rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline   ({nfwd} forwards incl. calibration/warm-up)",
          "NOTE: the forward runs its independent branches on side streams, so kernels overlap: per-kernel durations are",
-         "inflated by sharing the chip and their sum exceeds the wall time of a forward (bench.py reports that, ~2.35 ms).",
+         "inflated by sharing the chip and their sum exceeds the wall time of a forward (bench.py reports that, ~2.1 ms).",
          "For non-overlapped per-kernel times run with VTI_SINGLE_STREAM=1.",
          f"{'kernel family':44s} {'calls':>7s} {'avg us':>10s} {'us/forward':>12s}"]
 for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
@@ -48,12 +48,12 @@ def pmc_sum(d, name):
     return tot, cnt
 ft, fc = pmc_sum("gpurun_out/_p2", "FETCH_SIZE")
 wt, wc = pmc_sum("gpurun_out/_p3", "WRITE_SIZE")
-nf = fc["decode_kernel"]; nw = wc["decode_kernel"]
+nf = fc["sppf_pool"]; nw = wc["sppf_pool"]
 res = {"note": "HBM traffic per forward (bs=64) from rocprofv3 PMC, separate passes; FETCH_SIZE x2 correction for gfx950 applied",
        "families": {}}
 for k in ft:
     fetch = ft[k] / nf * 1024 * 2; write = wt.get(k, 0.0) / max(nw, 1) * 1024
     res["families"][k] = {"fetch_bytes": fetch, "write_bytes": write, "total_bytes": fetch + write}
 json.dump(res, open(f"{out}/{tag}_hbm_traffic.json", "w"), indent=1)
-print(json.dumps(res["families"].get("conv family (conv_kernel + conv3_pk + stem_kernel)"), indent=1))
+print(json.dumps(res["families"].get("conv family (conv3_pk + conv1_pk + conv_kernel + stem_l1_kernel)"), indent=1))
 PY

@@ -127,24 +127,42 @@ size_t nms_workspace_bytes(int B, int A) { return nms_layout(A).per_frame * (siz
 __global__ __launch_bounds__(256) void nms_scan_kernel(const float* __restrict__ pred, int A, int nc, int nm, float conf,
                                                        char* ws, NmsWsLayout L, int* __restrict__ ncand) {
     const int b = blockIdx.y;
-    const int a = blockIdx.x * 256 + threadIdx.x;
-    if (a >= A) return;
     const int no = 4 + nc + nm;
-    const float* P = pred + ((size_t)b * A + a) * no;      // pred is anchor-major: [B, A, 4+nc+nm]
-    float best = P[4];
+    float best;
     int j = 0;
-    int c = 1;
-    for (; c + 8 <= nc; c += 8) {            // 8 independent loads in flight, then the ordered compares
-        float v[8];
+    int a;
+    if (((no | nc) & 3) == 0) {
+        // anchor-major rows: four lanes share an anchor and read its class scores as 16-byte pieces (a wave instruction
+        // covers 16 rows x 64 contiguous bytes instead of 64 rows x 4 bytes); (value, first index) max across the quad
+        a = blockIdx.x * 64 + (threadIdx.x >> 2);
+        const int q = threadIdx.x & 3;
+        best = -INFINITY; j = 0x7fffffff;
+        if (a < A) {
+            const float4* row = (const float4*)(pred + ((size_t)b * A + a) * no + 4);
+            for (int i = q; i < (nc >> 2); i += 4) {
+                const float4 v = row[i];
+                if (v.x > best) { best = v.x; j = 4 * i; }
+                if (v.y > best) { best = v.y; j = 4 * i + 1; }
+                if (v.z > best) { best = v.z; j = 4 * i + 2; }
+                if (v.w > best) { best = v.w; j = 4 * i + 3; }
+            }
+        }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = P[4 + c + u];
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-            if (v[u] > best) { best = v[u]; j = c + u; }
-    }
-    for (; c < nc; ++c) {
-        const float v = P[4 + c];
-        if (v > best) { best = v; j = c; }
+        for (int o = 1; o <= 2; o <<= 1) {
+            const float ob = __shfl_xor(best, o);
+            const int oj = __shfl_xor(j, o);
+            if (ob > best || (ob == best && oj < j)) { best = ob; j = oj; }
+        }
+        if (q != 0 || a >= A) return;
+    } else {
+        a = blockIdx.x * 256 + threadIdx.x;
+        if (a >= A) return;
+        const float* P = pred + ((size_t)b * A + a) * no;      // pred is anchor-major: [B, A, 4+nc+nm]
+        best = P[4];
+        for (int c = 1; c < nc; ++c) {
+            const float v = P[4 + c];
+            if (v > best) { best = v; j = c; }
+        }
     }
     if (best > conf) {
         char* wsb = ws + (size_t)b * L.per_frame;
@@ -377,7 +395,8 @@ hipError_t launch_nms(const float* pred, int B, int A, int nc, int nm, float con
     int* ncand = (int*)((char*)ws + L.per_frame * (size_t)B);
     hipError_t e = hipMemsetAsync(ncand, 0, sizeof(int) * (size_t)B, st);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(nms_scan_kernel, dim3((A + 255) / 256, B), dim3(256), 0, st, pred, A, nc, nm, conf, (char*)ws, L, ncand);
+    const int apb = (((4 + nc + nm) | nc) & 3) == 0 ? 64 : 256;        // anchors per block: quad-per-anchor / lane-per-anchor
+    hipLaunchKernelGGL(nms_scan_kernel, dim3((A + apb - 1) / apb, B), dim3(256), 0, st, pred, A, nc, nm, conf, (char*)ws, L, ncand);
     hipLaunchKernelGGL(nms_kernel, dim3(B), dim3(NMS_THREADS), lds, st, pred, A, nc, nm, conf, iou, max_det, agnostic,
                        dets, counts, (char*)ws, L, ncand);
 #ifdef VTI_STAMPS
