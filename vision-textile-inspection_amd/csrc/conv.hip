@@ -298,10 +298,10 @@ __global__ __launch_bounds__(256) void stem_kernel(const ConvParams p) {
 //            layer 1's zero padding
 //   phase 3  layer 1 as implicit GEMM straight from that LDS tile: Cin = 16, so one 32-deep fp16 MFMA step covers TWO taps
 //            (lane group g -> tap 2s + (g >> 1), channels 8 (g & 1) ..; fp32: one tap per 16-deep step); 5 (9) steps
-//   phase 4  the shared epilogue (bias, SiLU, NHWC stores) on layer 1's 16 x 20 output tile
+//   phase 4  the shared epilogue (bias, SiLU, NHWC stores) on layer 1's 8 x 40 output tile
 // ConvParams roles: in = u8 frames [B, Hin, Win, 3]; wpk / bias / out / Cout / Hout / Wout describe LAYER 1;
 // w2 / bias2 = the stem's packed weights / bias.
-constexpr int SL_TH = 16, SL_TW = 20;
+constexpr int SL_TH = 8, SL_TW = 40;       // 35 patch rows of 489 B: the u8 reads are DRAM-bound on segment length (20-wide tiles: 252 B, 2x slower staging)
 constexpr int SL_SH = 2 * SL_TH + 1, SL_SW = 2 * SL_TW + 1, SL_NSP = SL_SH * SL_SW;       // stem pixels per tile
 constexpr int SL_RH = 4 * SL_TH + 3, SL_RWB = (4 * SL_TW + 3) * 3, SL_RWD = (SL_RWB + 6) >> 2, SL_PITCH = SL_RWD * 4;
 
@@ -337,46 +337,54 @@ __global__ __launch_bounds__(256) void stem_l1_kernel(const ConvParams p) {
     VTI_STAMP(0);
     // ---- phase 1: u8 -> T(v / 255) while staging.  fp16: v * (1/255) rounds to the same half as v / 255 for all 256 byte
     // values (checked exhaustively), so no table and no division; fp32 divides (what torch's `im.float() / 255` does).
-    {   // wave w stages rows w, w+4, ...; lane = dword of the row: all row arithmetic is scalar, the column test is done once,
-        // and every load of the wave is issued before the first one is consumed
-        constexpr int NIT = (SL_RH + 3) / 4;
-        static_assert(SL_RWD <= 64, "one lane per dword of a patch row");
-        const int gx = a0 + 4 * lane;
-        const bool col_ok = lane < SL_RWD && gx >= 0 && gx < rowbytes;
-        unsigned vv[NIT];
+    {   // wave w stages rows w, w+4, ...; a row is SL_RWD dwords = RC lane-chunks: all row arithmetic is scalar, the column test
+        // is done once per chunk, and every load of the wave is issued (branch-free) before the first one is consumed
+        constexpr int RC = (SL_RWD + 63) / 64, NR = (SL_RH + 3) / 4;
+        unsigned vv[NR][RC];
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
+        for (int it = 0; it < NR; ++it) {
             const int ry = wave + 4 * it;
             const int y = iy0 + ry;
-            unsigned v = 0;
             const bool row_ok = ry < SL_RH && (unsigned)y < (unsigned)p.Hin;
-            if ((rowbytes & 3) == 0) {
-                // branch-free: an unconditional load from a clamped address, then a select (a load inside a branch makes the
-                // compiler wait for it at the join, which serialises the 17 round trips)
-                const bool ok = row_ok && col_ok;
-                const unsigned ld = *(const unsigned*)(inb + (ok ? (size_t)y * rowbytes + gx : (size_t)0));
-                v = ok ? ld : 0u;
-            } else if (row_ok && lane < SL_RWD) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (gx + k >= 0 && gx + k < rowbytes) v |= (unsigned)inb[(size_t)y * rowbytes + gx + k] << (8 * k);
+            for (int ch = 0; ch < RC; ++ch) {
+                const int rd = lane + 64 * ch;
+                const int gx = a0 + 4 * rd;
+                unsigned v = 0;
+                if ((rowbytes & 3) == 0) {
+                    const bool ok = row_ok && rd < SL_RWD && gx >= 0 && gx < rowbytes;
+#ifdef VTI_STAMPS
+                    const unsigned ld = *(const unsigned*)(inb + (ok ? (p.pk_depth == 77 ? (size_t)(4 * lane) : (size_t)y * rowbytes + gx) : (size_t)0));   // pk_depth == 77: experiment (hot lines only)
+#else
+                    const unsigned ld = *(const unsigned*)(inb + (ok ? (size_t)y * rowbytes + gx : (size_t)0));
+#endif
+                    v = ok ? ld : 0u;
+                } else if (row_ok && rd < SL_RWD) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (gx + k >= 0 && gx + k < rowbytes) v |= (unsigned)inb[(size_t)y * rowbytes + gx + k] << (8 * k);
+                }
+                vv[it][ch] = v;
             }
-            vv[it] = v;
         }
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
+        for (int it = 0; it < NR; ++it) {
             const int ry = wave + 4 * it;
-            if (ry >= SL_RH || lane >= SL_RWD) continue;
-            const unsigned v = vv[it];
-            T* o = cp + (size_t)ry * SL_PITCH + 4 * lane;
-            if constexpr (sizeof(T) == 2) {
-                half4 hv;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) hv[k] = (half_t)((float)((v >> (8 * k)) & 0xffu) * (1.0f / 255.0f));
-                *(half4*)o = hv;
-            } else {
+            for (int ch = 0; ch < RC; ++ch) {
+                const int rd = lane + 64 * ch;
+                if (ry >= SL_RH || rd >= SL_RWD) continue;
+                const unsigned v = vv[it][ch];
+                T* o = cp + (size_t)ry * SL_PITCH + 4 * rd;
+                if constexpr (sizeof(T) == 2) {
+                    half4 hv;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) o[k] = (float)((v >> (8 * k)) & 0xffu) / 255.0f;
+                    for (int k = 0; k < 4; ++k) hv[k] = (half_t)((float)((v >> (8 * k)) & 0xffu) * (1.0f / 255.0f));
+                    *(half4*)o = hv;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) o[k] = (float)((v >> (8 * k)) & 0xffu) / 255.0f;
+                }
             }
         }
     }
@@ -479,11 +487,19 @@ __global__ __launch_bounds__(256) void stem_l1_kernel(const ConvParams p) {
     VTI_STAMP(12);
 }
 
+void stem_l1_tile(int* th, int* tw) { *th = SL_TH; *tw = SL_TW; }
+
 hipError_t launch_stem_l1(int dtype, const ConvParams& p, hipStream_t st) {
     dim3 grid((unsigned)(p.B * p.tiles_y * p.tiles_x));
     if (grid.x == 0) return hipSuccess;
     const size_t lds = stem_l1_lds_bytes(dtype);
     if (dtype == VTI_F16) {
+        static bool attr16 = false;
+        if (!attr16) {
+            hipError_t e = hipFuncSetAttribute((const void*)stem_l1_kernel<half_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+            attr16 = true;
+        }
         hipLaunchKernelGGL(stem_l1_kernel<half_t>, grid, dim3(256), lds, st, p);
     } else {
         static bool attr_done = false;

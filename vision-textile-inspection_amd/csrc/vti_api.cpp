@@ -118,7 +118,7 @@ int32_t vti_conv_at(const vti_ctx* c, int32_t i, vti_conv_info* o) {
             o->tile_h = op.cfg.TH; o->tile_w = op.cfg.TW; o->waves_n = op.cfg.WN; o->nrep = op.cfg.NREP;
             o->lds_bytes = (int32_t)op.cfg.lds; o->persistent = op.cfg.pk;   // 1: conv3_pk, 2: conv1_pk
         } else if (op.fused_l1 == i) {  // layer 1 inside the stem's kernel (stem_l1_kernel: 16 x 20 output tiles, 2 n-tiles)
-            o->tile_h = 16; o->tile_w = 20; o->waves_n = 1; o->nrep = 2; o->lds_bytes = 0; o->fused = 1;
+            stem_l1_tile(&o->tile_h, &o->tile_w); o->waves_n = 1; o->nrep = 2; o->lds_bytes = 0; o->fused = 1;
         } else if (op.fused == i) {     // runs inside its producer's kernel, on that kernel's geometry
             o->tile_h = op.cfg.TH; o->tile_w = op.cfg.TW; o->waves_n = 1; o->nrep = op.cfg.ntiles2;
             o->lds_bytes = 0; o->fused = 1;
@@ -312,7 +312,8 @@ int32_t vti_forward(vti_ctx* c, const uint8_t* input, int32_t B, int32_t swap_rb
                 q.out = buf_ptr(c, op.out2.buf, input, proto); q.out_ld = o1.C; q.out_coff = op.out2.coff;
                 q.wpk = (const char*)c->d_wpk + g.wpk_off2; q.bias = c->d_bias + g.bias_off2;     // layer 1
                 q.w2 = (const char*)c->d_wpk + g.wpk_off; q.bias2 = c->d_bias + g.bias_off;       // stem
-                q.TH = 16; q.TW = 20; q.tiles_y = (q.Hout + 15) / 16; q.tiles_x = (q.Wout + 19) / 20; q.WN = 1;
+                stem_l1_tile(&q.TH, &q.TW);
+                q.tiles_y = (q.Hout + q.TH - 1) / q.TH; q.tiles_x = (q.Wout + q.TW - 1) / q.TW; q.WN = 1;
                 q.scalar_store = (q.out_ld % 4 || q.out_coff % 4) ? 1 : 0;
 #ifdef VTI_STAMPS
                 if (const char* so = getenv("VTI_STAMP_OP")) {
@@ -322,6 +323,7 @@ int32_t vti_forward(vti_ctx* c, const uint8_t* input, int32_t B, int32_t swap_rb
                         if (hipMalloc((void**)&d_st, nwg * 16 * 8) == hipSuccess) {
                             (void)hipMemset(d_st, 0, nwg * 16 * 8);
                             q.stamps = d_st;
+                            q.pk_depth = getenv("VTI_EXPT") ? 77 : 0;
                             (void)launch_stem_l1(dt, q, st);
                             (void)hipStreamSynchronize(st);
                             std::vector<unsigned long long> h(nwg * 16);
@@ -329,7 +331,7 @@ int32_t vti_forward(vti_ctx* c, const uint8_t* input, int32_t B, int32_t swap_rb
                             (void)hipFree(d_st);
                             fprintf(stderr, "[stamps] op %s + layer 1 (1: patch staged, 2: stem done, 3: layer-1 MFMAs done, 12: end)\n", so);
                             report_stamps(h, nwg, false);
-                            q.stamps = nullptr;
+                            q.stamps = nullptr; q.pk_depth = 0;
                         }
                     }
                 }

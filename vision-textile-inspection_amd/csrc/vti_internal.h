@@ -129,6 +129,7 @@ bool conv_cfg_fits(int ks, int stride, int mode, int TH, int TW, int WN, int NRE
 // stem (3->16, k3 s2) + layer 1 (16->32, k3 s2) in one kernel: 16 x 20 layer-1 output tiles
 hipError_t launch_stem_l1(int dtype, const ConvParams& p, hipStream_t st);
 size_t stem_l1_lds_bytes(int dtype);
+void stem_l1_tile(int* th, int* tw);
 void pack_conv_l1pairs(int dtype, const ConvRow& r1, const float* w, const float* b, uint8_t* dst_w, float* dst_b);
 size_t packed_l1pairs_bytes(int dtype);
 // conv_pk.hip: persistent 3x3/s1 kernel
