@@ -353,11 +353,7 @@ __global__ __launch_bounds__(256) void stem_l1_kernel(const ConvParams p) {
                 unsigned v = 0;
                 if ((rowbytes & 3) == 0) {
                     const bool ok = row_ok && rd < SL_RWD && gx >= 0 && gx < rowbytes;
-#ifdef VTI_STAMPS
-                    const unsigned ld = *(const unsigned*)(inb + (ok ? (p.pk_depth == 77 ? (size_t)(4 * lane) : (size_t)y * rowbytes + gx) : (size_t)0));   // pk_depth == 77: experiment (hot lines only)
-#else
                     const unsigned ld = *(const unsigned*)(inb + (ok ? (size_t)y * rowbytes + gx : (size_t)0));
-#endif
                     v = ok ? ld : 0u;
                 } else if (row_ok && rd < SL_RWD) {
 #pragma unroll

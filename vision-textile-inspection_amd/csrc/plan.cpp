@@ -158,8 +158,7 @@ static bool choose_pk1_cfg(int esize, const ConvRow& r, int max_batch, ConvCfg& 
     // 20 x 20 maps (a tile's worth of pixels per CU: nothing to pipeline) and on the ConvTranspose scatter epilogue
     const bool forced = fth || fwn || fnrep;
     const char* all1 = getenv("VTI_PK1_ALL");
-    const char* dc1 = getenv("VTI_PK1_DECONV");
-    if (!forced && !(all1 && all1[0] == '1') && ((deconv && !(dc1 && dc1[0] == '1')) || r.h_out * r.w_out < 1600)) return false;
+    if (!forced && !(all1 && all1[0] == '1') && (deconv || r.h_out * r.w_out < 1600)) return false;
     const long total_px = (long)max_batch * (deconv ? r.h_in * r.w_in : r.h_out * r.w_out);
     double best = 1e30;
     bool found = false;
@@ -506,9 +505,7 @@ std::string Plan::build(const vti_desc& d) {
         macs += r.macs(); fused_params += r.fused_params();
         if (op.fused >= 0) {   // whole Cout in one wave; the per-tile kernel (2 workgroups per CU) hides the long fused epilogue better
             const char* pf = getenv("VTI_PK_FUSED");
-            const char* pp = getenv("VTI_PK_FUSED_PROTO");
-            choose_conv_cfg(d.dtype, r, false, d.max_batch, op.cfg, 0, 0, 1, r.c2 / 16,
-                            (pf && pf[0] == '1') || (pp && pp[0] == '1' && r.name == "model.22.proto.cv2"));
+            choose_conv_cfg(d.dtype, r, false, d.max_batch, op.cfg, 0, 0, 1, r.c2 / 16, pf && pf[0] == '1');
         }
         else if (op.fused_l1 >= 0) choose_conv_cfg(d.dtype, r, true, d.max_batch, op.cfg, 0, 0, 1, 1);   // one 16-channel n-tile: stem_l1_kernel's weight indexing
         else choose_conv_cfg(d.dtype, r, op.kind == OP_CONV0, d.max_batch, op.cfg);

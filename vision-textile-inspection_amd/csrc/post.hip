@@ -565,7 +565,7 @@ __global__ __launch_bounds__(256) void masks_kernel(const float* __restrict__ de
         // bilinear weights are separable and the interpolation is linear in its four taps: blend the two low-res rows first
         // (6 columns per thread), then 16 pixels x one horizontal blend -- 66 instead of 144 flops per thread.  (torch blends
         // horizontally first; the two orders differ by fp32 rounding only, i.e. at pixels whose value is within ~1e-7 of the
-        // threshold.  The mask gate is IoU >= 0.999 against the oracle, tests/test_gpu_postproc.py.)
+        // threshold.  The mask gate is IoU >= 0.999 against the CPU reference, tests/test_gpu_postproc.py.)
         float cv[6];
 #pragma unroll
         for (int k = 0; k < 6; ++k) cv[k] = r0[k] * lyw0 + r1[k] * ly1;

@@ -323,7 +323,6 @@ int32_t vti_forward(vti_ctx* c, const uint8_t* input, int32_t B, int32_t swap_rb
                         if (hipMalloc((void**)&d_st, nwg * 16 * 8) == hipSuccess) {
                             (void)hipMemset(d_st, 0, nwg * 16 * 8);
                             q.stamps = d_st;
-                            q.pk_depth = getenv("VTI_EXPT") ? 77 : 0;
                             (void)launch_stem_l1(dt, q, st);
                             (void)hipStreamSynchronize(st);
                             std::vector<unsigned long long> h(nwg * 16);
@@ -331,7 +330,7 @@ int32_t vti_forward(vti_ctx* c, const uint8_t* input, int32_t B, int32_t swap_rb
                             (void)hipFree(d_st);
                             fprintf(stderr, "[stamps] op %s + layer 1 (1: patch staged, 2: stem done, 3: layer-1 MFMAs done, 12: end)\n", so);
                             report_stamps(h, nwg, false);
-                            q.stamps = nullptr; q.pk_depth = 0;
+                            q.stamps = nullptr;
                         }
                     }
                 }
