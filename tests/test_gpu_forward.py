@@ -124,3 +124,26 @@ def test_full_size_batch_properties():
     from oracle.model import OracleModel
     opred, _ = OracleModel(blob, 640, 640, "fp16").forward_u8(base[:2])
     assert (pred[:2, 4:84].cpu() - opred[:, 4:84]).abs().max() < 2e-2
+
+
+def test_batch_and_geometry_invariance_at_full_size():
+    """BASELINE size (64 frames of 640x640): every frame's pred/proto must be BIT-identical to what the same engine code
+    produces for that frame in a 3-frame batch -- the plans differ (tile shapes, persistent tile chains, workgroups per
+    layer are chosen per max_batch), the arithmetic per output element must not.  Size-independent property: no oracle."""
+    need_gpu()
+    import vti_amd
+    fr = frames_u8(64, 640, 640, seed=11)
+    big = vti_amd.Engine("n", 80, H=640, W=640, max_batch=64, dtype="fp16")
+    blob = vti_amd.random_weights(big, 1, cls_bias=-6.0)
+    big.load_weights(blob, 0)
+    small = vti_amd.Engine("n", 80, H=640, W=640, max_batch=3, dtype="fp16")
+    small.load_weights(blob, 0)
+    x = torch.from_numpy(fr).cuda()
+    pred, proto = big.forward(x, swap_rb=True)
+    torch.cuda.synchronize()
+    assert torch.isfinite(pred).all() and torch.isfinite(proto.float()).all()
+    for lo in (0, 30, 61):
+        p3, q3 = small.forward(x[lo:lo + 3].contiguous(), swap_rb=True)
+        torch.cuda.synchronize()
+        assert torch.equal(p3, pred[lo:lo + 3]), f"pred differs for frames {lo}..{lo + 2}: max|d|={(p3 - pred[lo:lo + 3]).abs().max().item():.3e}"
+        assert torch.equal(q3, proto[lo:lo + 3]), f"proto differs for frames {lo}..{lo + 2}"
