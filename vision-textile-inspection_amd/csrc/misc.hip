@@ -56,49 +56,50 @@ __global__ __launch_bounds__(256) void sppf_pool_kernel(const PoolParams p) {
     }
 }
 
-// Fast path: one workgroup per (frame, 16-B channel group); the whole H x W map of that group sits in
-// LDS and the three chained 5x5 pools run as separable row/column passes -- exactly the reference's
-// chained MaxPool2d(5,1,2) (max is exact, so fp16/fp32 results are bit-identical to the chained form).
-template <typename T>
+// Fast path: one workgroup per (frame, group of G 16-byte channel pieces); the whole H x W map of that group sits in
+// LDS and the three chained 5x5 pools run as separable row/column passes -- exactly the reference's chained
+// MaxPool2d(5,1,2) (max is exact, so fp16/fp32 results are bit-identical to the chained form).  G consecutive lanes
+// touch G x 16 contiguous bytes of one pixel (G = 4: 64-byte segments instead of one 16-byte piece per 1-KiB pixel row).
+template <typename T, int G>
 __global__ __launch_bounds__(256) void sppf_pool_lds_kernel(const PoolParams p) {
     using vec = typename V16<T>::vec;
     constexpr int N = V16<T>::N;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int HW = p.H * p.W;
-    vec* cur = (vec*)smem;              // [HW]
-    vec* tmp = cur + HW;                // [HW]
-    const int cv = p.C / N;
-    const int b = blockIdx.x / cv, c = blockIdx.x - b * cv;
-    const T* in = (const T*)p.in + (size_t)b * HW * p.ld + p.in_coff + c * N;
-    T* out = (T*)p.out + (size_t)b * HW * p.ld + p.out_coff + c * N;
-    for (int i = threadIdx.x; i < HW; i += 256) cur[i] = *(const vec*)(in + (size_t)i * p.ld);
+    vec* cur = (vec*)smem;              // [HW][G]
+    vec* tmp = cur + HW * G;            // [HW][G]
+    const int cg = p.C / (N * G);
+    const int b = blockIdx.x / cg, c = blockIdx.x - b * cg;
+    const T* in = (const T*)p.in + (size_t)b * HW * p.ld + p.in_coff + c * (N * G);
+    T* out = (T*)p.out + (size_t)b * HW * p.ld + p.out_coff + c * (N * G);
+    for (int i = threadIdx.x; i < HW * G; i += 256) cur[i] = *(const vec*)(in + (size_t)(i / G) * p.ld + (i % G) * N);
     __syncthreads();
     for (int pass = 0; pass < 3; ++pass) {
-        for (int i = threadIdx.x; i < HW; i += 256) {       // row pass: max over x-2..x+2
-            const int y = i / p.W, x = i - y * p.W;
+        for (int i = threadIdx.x; i < HW * G; i += 256) {   // row pass: max over x-2..x+2
+            const int pix = i / G, v_ = i - pix * G;
+            const int y = pix / p.W, x = pix - y * p.W;
             vec m = cur[i];
             for (int d = -2; d <= 2; ++d) {
                 const int xx = x + d;
                 if (d == 0 || (unsigned)xx >= (unsigned)p.W) continue;
-                const vec v = cur[y * p.W + xx];
-#pragma unroll
-                for (int j = 0; j < N; ++j) m[j] = v[j] > m[j] ? v[j] : m[j];
+                const vec v = cur[(y * p.W + xx) * G + v_];
+                m = __builtin_elementwise_max(m, v);         // v_pk_max_f16 / v_max_f32: 4 instructions per 16-byte piece
             }
             tmp[i] = m;
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < HW; i += 256) {       // column pass + store this pool level
-            const int y = i / p.W, x = i - y * p.W;
+        for (int i = threadIdx.x; i < HW * G; i += 256) {   // column pass + store this pool level
+            const int pix = i / G, v_ = i - pix * G;
+            const int y = pix / p.W, x = pix - y * p.W;
             vec m = tmp[i];
             for (int d = -2; d <= 2; ++d) {
                 const int yy = y + d;
                 if (d == 0 || (unsigned)yy >= (unsigned)p.H) continue;
-                const vec v = tmp[yy * p.W + x];
-#pragma unroll
-                for (int j = 0; j < N; ++j) m[j] = v[j] > m[j] ? v[j] : m[j];
+                const vec v = tmp[(yy * p.W + x) * G + v_];
+                m = __builtin_elementwise_max(m, v);         // v_pk_max_f16 / v_max_f32: 4 instructions per 16-byte piece
             }
             cur[i] = m;
-            *(vec*)(out + (size_t)i * p.ld + pass * p.C) = m;
+            *(vec*)(out + (size_t)pix * p.ld + pass * p.C + v_ * N) = m;
         }
         __syncthreads();
     }
@@ -108,11 +109,17 @@ hipError_t launch_sppf_pool(int dtype, const PoolParams& p, hipStream_t st) {
     const int N = dtype == VTI_F16 ? 8 : 4;
     const long total = (long)p.B * p.H * p.W * (p.C / N);
     if (total == 0) return hipSuccess;
-    const size_t lds = (size_t)2 * p.H * p.W * 16;
-    if (lds <= 64 * 1024) {
+    const size_t lds1 = (size_t)2 * p.H * p.W * 16;
+    if (lds1 * 4 <= 64 * 1024 && p.C % (4 * N) == 0) {      // four 16-byte pieces per workgroup: 64-byte global segments
+        const int grid = p.B * (p.C / (4 * N));
+        if (dtype == VTI_F16) hipLaunchKernelGGL((sppf_pool_lds_kernel<half_t, 4>), dim3(grid), dim3(256), lds1 * 4, st, p);
+        else hipLaunchKernelGGL((sppf_pool_lds_kernel<float, 4>), dim3(grid), dim3(256), lds1 * 4, st, p);
+        return hipGetLastError();
+    }
+    if (lds1 <= 64 * 1024) {
         const int grid = p.B * (p.C / N);
-        if (dtype == VTI_F16) hipLaunchKernelGGL(sppf_pool_lds_kernel<half_t>, dim3(grid), dim3(256), lds, st, p);
-        else hipLaunchKernelGGL(sppf_pool_lds_kernel<float>, dim3(grid), dim3(256), lds, st, p);
+        if (dtype == VTI_F16) hipLaunchKernelGGL((sppf_pool_lds_kernel<half_t, 1>), dim3(grid), dim3(256), lds1, st, p);
+        else hipLaunchKernelGGL((sppf_pool_lds_kernel<float, 1>), dim3(grid), dim3(256), lds1, st, p);
         return hipGetLastError();
     }
     const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
