@@ -1,6 +1,10 @@
 // Implicit-GEMM convolution for gfx950 (MI355X): NHWC activations, MFMA 16x16x32 f16 (or the
 // exact-f32 16x16x4 form), fp32 accumulate, fused bias + SiLU (+ residual) epilogue.
 //
+// This file: the per-tile kernel family (`conv_kernel`: 3x3 s1/s2, 1x1, ConvTranspose; with the register-level fused 1x1
+// second stage of the head towers / proto), the standalone stem and the fused stem + layer-1 kernel.  The persistent
+// LDS-DMA kernels for 3x3/s1 and 1x1 convs live in conv_pk.hip; both share conv_dev.h.  launch_conv() dispatches.
+//
 // Implements the Conv-BN-SiLU / Conv2d / ConvTranspose2d(2,2) rows of the YOLOv8-seg table
 //  that run behind the reference's model.predict()
 // (measurement.py:208-210).

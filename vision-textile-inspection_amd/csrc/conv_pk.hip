@@ -1,4 +1,5 @@
-// Persistent implicit-GEMM 3x3 / stride-1 convolution for gfx950 (MI355X) with LDS-DMA operand prefetch.
+// Persistent implicit-GEMM convolutions for gfx950 (MI355X) with LDS-DMA operand prefetch: conv3_pk (3x3 / stride 1, described
+// first) and conv1_pk (1x1, further down).
 //
 // Same GEMM view, MFMA operand roles, weight packing and epilogue contract as conv.hip (Conv-BN-SiLU rows of
 // the YOLOv8-seg table, SURVEY.md section 8 U2-U5, behind measurement.py:208-210), different schedule:
