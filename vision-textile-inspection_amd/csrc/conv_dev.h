@@ -342,6 +342,28 @@ __device__ __forceinline__ void conv_stage2(const ConvParams& p, f32x4 (&acc)[MR
             return;
         }
     }
+    if constexpr (sizeof(T) == 2 && NREP2 % 2 == 0) {
+        // fp16 output with permuted rows (proto.cv3): the lane's 4*NREP2 channels are consecutive, so tile pairs go out as
+        // 16-byte stores and the four lane groups of a pixel write 64 contiguous bytes per instruction
+        if (!p.nat2 && !p.out2_f32 && !p.scalar_store2 && (p.Cout2 & 7) == 0 && ((p.out2_ld | p.out2_coff) & 7) == 0) {
+#pragma unroll
+            for (int m = 0; m < MREP; ++m) {
+                if (!pvalid[m]) continue;
+                half_t* op = (half_t*)p.out2 + ((size_t)b * p.out2_bstride + (size_t)opy[m] * p.Wout + opx[m]) * p.out2_ld + p.out2_coff + crun2;
+#pragma unroll
+                for (int n = 0; n < NREP2; n += 2) {
+                    if (crun2 + 4 * n >= p.Cout2) continue;
+                    f32x4 v0 = acc2[m][n] + bias2[n], v1 = acc2[m][n + 1] + bias2[n + 1];
+                    if (p.act2 == 1) { v0 = silu4<FAST>(v0); v1 = silu4<FAST>(v1); }
+                    half8 hv;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { hv[j] = (half_t)v0[j]; hv[4 + j] = (half_t)v1[j]; }
+                    *(half8*)(op + 4 * n) = hv;
+                }
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int m = 0; m < MREP; ++m) {
         if (!pvalid[m]) continue;
