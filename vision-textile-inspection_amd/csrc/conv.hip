@@ -345,26 +345,54 @@ __global__ __launch_bounds__(256) void stem_l1_kernel(const ConvParams p) {
         // is done once per chunk, and every load of the wave is issued (branch-free) before the first one is consumed
         constexpr int RC = (SL_RWD + 63) / 64, NR = (SL_RH + 3) / 4;
         unsigned vv[NR][RC];
+        if ((rowbytes & 3) == 0) {
+            // straight-line code: every load is unconditional (clamped address) and NOTHING consumes a result inside this
+            // block -- a select or a branch per load makes the compiler wait for each one (18 serialised round trips:
+            // 20 k cycles per workgroup, measured).  The masks are re-derived after the loads.
 #pragma unroll
-        for (int it = 0; it < NR; ++it) {
-            const int ry = wave + 4 * it;
-            const int y = iy0 + ry;
-            const bool row_ok = ry < SL_RH && (unsigned)y < (unsigned)p.Hin;
+            for (int it = 0; it < NR; ++it) {
+                const int ry = wave + 4 * it;
+                const int y = iy0 + ry;
+                const bool row_ok = ry < SL_RH && (unsigned)y < (unsigned)p.Hin;
 #pragma unroll
-            for (int ch = 0; ch < RC; ++ch) {
-                const int rd = lane + 64 * ch;
-                const int gx = a0 + 4 * rd;
-                unsigned v = 0;
-                if ((rowbytes & 3) == 0) {
+                for (int ch = 0; ch < RC; ++ch) {
+                    const int rd = lane + 64 * ch;
+                    const int gx = a0 + 4 * rd;
                     const bool ok = row_ok && rd < SL_RWD && gx >= 0 && gx < rowbytes;
-                    const unsigned ld = *(const unsigned*)(inb + (ok ? (size_t)y * rowbytes + gx : (size_t)0));
-                    v = ok ? ld : 0u;
-                } else if (row_ok && rd < SL_RWD) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        if (gx + k >= 0 && gx + k < rowbytes) v |= (unsigned)inb[(size_t)y * rowbytes + gx + k] << (8 * k);
+                    vv[it][ch] = *(const unsigned*)(inb + (ok ? (size_t)y * rowbytes + gx : (size_t)0));
                 }
-                vv[it][ch] = v;
+            }
+#pragma unroll
+            for (int it = 0; it < NR; ++it) {
+                const int ry = wave + 4 * it;
+                const int y = iy0 + ry;
+                const bool row_ok = ry < SL_RH && (unsigned)y < (unsigned)p.Hin;
+#pragma unroll
+                for (int ch = 0; ch < RC; ++ch) {
+                    const int rd = lane + 64 * ch;
+                    const int gx = a0 + 4 * rd;
+                    const bool ok = row_ok && rd < SL_RWD && gx >= 0 && gx < rowbytes;
+                    vv[it][ch] = ok ? vv[it][ch] : 0u;
+                }
+            }
+        } else {                    // ragged width (tests only): assemble byte by byte
+#pragma unroll
+            for (int it = 0; it < NR; ++it) {
+                const int ry = wave + 4 * it;
+                const int y = iy0 + ry;
+                const bool row_ok = ry < SL_RH && (unsigned)y < (unsigned)p.Hin;
+#pragma unroll
+                for (int ch = 0; ch < RC; ++ch) {
+                    const int rd = lane + 64 * ch;
+                    const int gx = a0 + 4 * rd;
+                    unsigned v = 0;
+                    if (row_ok && rd < SL_RWD) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (gx + k >= 0 && gx + k < rowbytes) v |= (unsigned)inb[(size_t)y * rowbytes + gx + k] << (8 * k);
+                    }
+                    vv[it][ch] = v;
+                }
             }
         }
 #pragma unroll
