@@ -228,6 +228,27 @@ __global__ __launch_bounds__(256) void stem_kernel(const ConvParams p) {
     const int y0 = oy0 * 2 - 1;
     const uint8_t* inb = (const uint8_t*)p.in + (size_t)b * p.Hin * p.Win * 3;
     const int rowbytes = p.Win * 3;                     // multiple of 4 in the product (W % 32 == 0)
+    if ((rowbytes & 3) == 0 && RH * RWD <= 8 * 256) {
+        // aligned rows, straight-line: all (unconditional, clamped) loads first, masks applied afterwards -- a load inside a
+        // branch is waited for at the join, one memory round trip per loop iteration
+        unsigned vv[8];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int i = tid + it * 256;
+            const int ry = (int)__umulhi((unsigned)i, p.rw_magic), rd = i - ry * RWD;
+            const int y = y0 + ry, gx = a0 + 4 * rd;
+            const bool ok = i < RH * RWD && (unsigned)y < (unsigned)p.Hin && gx >= 0 && gx < rowbytes;
+            vv[it] = *(const unsigned*)(inb + (ok ? (size_t)y * rowbytes + gx : (size_t)0));
+        }
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int i = tid + it * 256;
+            const int ry = (int)__umulhi((unsigned)i, p.rw_magic), rd = i - ry * RWD;
+            const int y = y0 + ry, gx = a0 + 4 * rd;
+            const bool ok = (unsigned)y < (unsigned)p.Hin && gx >= 0 && gx < rowbytes;
+            if (i < RH * RWD) raw32[i] = ok ? vv[it] : 0u;
+        }
+    } else
     for (int i = tid; i < RH * RWD; i += 256) {
         const int ry = (int)__umulhi((unsigned)i, p.rw_magic), rd = i - ry * RWD;
         const int y = y0 + ry, gx = a0 + 4 * rd;

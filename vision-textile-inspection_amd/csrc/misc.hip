@@ -72,7 +72,25 @@ __global__ __launch_bounds__(256) void sppf_pool_lds_kernel(const PoolParams p) 
     const int b = blockIdx.x / cg, c = blockIdx.x - b * cg;
     const T* in = (const T*)p.in + (size_t)b * HW * p.ld + p.in_coff + c * (N * G);
     T* out = (T*)p.out + (size_t)b * HW * p.ld + p.out_coff + c * (N * G);
-    for (int i = threadIdx.x; i < HW * G; i += 256) cur[i] = *(const vec*)(in + (size_t)(i / G) * p.ld + (i % G) * N);
+    {   // all loads first (a load consumed inside the loop body is one memory round trip per iteration)
+        constexpr int MAXIT = 8;
+        if (HW * G <= MAXIT * 256) {
+            vec r[MAXIT];
+#pragma unroll
+            for (int it = 0; it < MAXIT; ++it) {
+                const int i = threadIdx.x + it * 256;
+                const int ic = i < HW * G ? i : 0;
+                r[it] = *(const vec*)(in + (size_t)(ic / G) * p.ld + (ic % G) * N);
+            }
+#pragma unroll
+            for (int it = 0; it < MAXIT; ++it) {
+                const int i = threadIdx.x + it * 256;
+                if (i < HW * G) cur[i] = r[it];
+            }
+        } else {
+            for (int i = threadIdx.x; i < HW * G; i += 256) cur[i] = *(const vec*)(in + (size_t)(i / G) * p.ld + (i % G) * N);
+        }
+    }
     __syncthreads();
     for (int pass = 0; pass < 3; ++pass) {
         for (int i = threadIdx.x; i < HW * G; i += 256) {   // row pass: max over x-2..x+2

@@ -139,12 +139,28 @@ __global__ __launch_bounds__(256) void nms_scan_kernel(const float* __restrict__
         best = -INFINITY; j = 0x7fffffff;
         if (a < A) {
             const float4* row = (const float4*)(pred + ((size_t)b * A + a) * no + 4);
-            for (int i = q; i < (nc >> 2); i += 4) {
-                const float4 v = row[i];
-                if (v.x > best) { best = v.x; j = 4 * i; }
-                if (v.y > best) { best = v.y; j = 4 * i + 1; }
-                if (v.z > best) { best = v.z; j = 4 * i + 2; }
-                if (v.w > best) { best = v.w; j = 4 * i + 3; }
+            constexpr int MAXV = 8;                 // up to 128 classes: every load of the lane is issued before the first compare
+            float4 v[MAXV];
+#pragma unroll
+            for (int u = 0; u < MAXV; ++u) {
+                const int i = q + 4 * u;
+                v[u] = row[i < (nc >> 2) ? i : 0];
+            }
+#pragma unroll
+            for (int u = 0; u < MAXV; ++u) {
+                const int i = q + 4 * u;
+                if (i >= (nc >> 2)) continue;
+                if (v[u].x > best) { best = v[u].x; j = 4 * i; }
+                if (v[u].y > best) { best = v[u].y; j = 4 * i + 1; }
+                if (v[u].z > best) { best = v[u].z; j = 4 * i + 2; }
+                if (v[u].w > best) { best = v[u].w; j = 4 * i + 3; }
+            }
+            for (int i = q + 4 * MAXV; i < (nc >> 2); i += 4) {
+                const float4 w = row[i];
+                if (w.x > best) { best = w.x; j = 4 * i; }
+                if (w.y > best) { best = w.y; j = 4 * i + 1; }
+                if (w.z > best) { best = w.z; j = 4 * i + 2; }
+                if (w.w > best) { best = w.w; j = 4 * i + 3; }
             }
         }
 #pragma unroll
