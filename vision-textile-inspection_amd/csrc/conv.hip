@@ -323,9 +323,11 @@ __global__ __launch_bounds__(256) void stem_kernel(const ConvParams p) {
 //            layer 1's zero padding
 //   phase 3  layer 1 as implicit GEMM straight from that LDS tile: Cin = 16, so one 32-deep fp16 MFMA step covers TWO taps
 //            (lane group g -> tap 2s + (g >> 1), channels 8 (g & 1) ..; fp32: one tap per 16-deep step); 5 (9) steps
-//   phase 4  the shared epilogue (bias, SiLU, NHWC stores) on layer 1's 8 x 40 output tile
+//   phase 4  the shared epilogue (bias, SiLU, NHWC stores) on layer 1's 8 x 40 output tile -- or, when the plan fused the 1x1
+//            conv that is layer 1's only consumer (model.2.cv1), that conv on layer 1's register tile (conv_stage2): then
+//            layer 1's tensor does not reach HBM either and only the third conv's output is stored
 // ConvParams roles: in = u8 frames [B, Hin, Win, 3]; wpk / bias / out / Cout / Hout / Wout describe LAYER 1;
-// w2 / bias2 = the stem's packed weights / bias.
+// w0 / bias0 = the stem's packed weights / bias; w2 / bias2 / out2 (non-null) = the fused third conv.
 constexpr int SL_TH = 8, SL_TW = 40;       // 35 patch rows of 489 B: the u8 reads are DRAM-bound on segment length (20-wide tiles: 252 B, 2x slower staging)
 constexpr int SL_SH = 2 * SL_TH + 1, SL_SW = 2 * SL_TW + 1, SL_NSP = SL_SH * SL_SW;       // stem pixels per tile
 constexpr int SL_RH = 4 * SL_TH + 3, SL_RWB = (4 * SL_TW + 3) * 3, SL_RWD = (SL_RWB + 6) >> 2, SL_PITCH = SL_RWD * 4;
@@ -452,9 +454,9 @@ __global__ __launch_bounds__(256) void stem_l1_kernel(const ConvParams p) {
                 const int kh = tap / 3, kw = tap - kh * 3;
                 off[c][j] = k < 27 ? kh * SL_PITCH + kw * 3 + (p.swap_rb ? 2 - chn : chn) : -1;
             }
-            w[c] = ((const vec*)p.w2)[(size_t)c * 64 + lane];          // one n-tile (16 stem channels)
+            w[c] = ((const vec*)p.w0)[(size_t)c * 64 + lane];          // one n-tile (16 stem channels)
         }
-        const f32x4 bias4 = *(const f32x4*)(p.bias2 + g * 4);
+        const f32x4 bias4 = *(const f32x4*)(p.bias0 + g * 4);
         constexpr int NMT = (SL_NSP + 15) / 16;
         constexpr int UN = 4;
         for (int mt0 = wave; mt0 < NMT; mt0 += 4 * UN) {
@@ -531,8 +533,9 @@ __global__ __launch_bounds__(256) void stem_l1_kernel(const ConvParams p) {
         }
     }
     VTI_STAMP(3);
-    // ---- phase 4
-    conv_epilogue<T, 2>(p, acc, pvalid, opy, opx, b, 0, 0, lane);
+    // ---- phase 4: layer 1's epilogue, or (model.2.cv1 fused) the 1x1 conv on layer 1's register tile
+    if (p.out2) conv_stage2<T, 2, 2>(p, acc, pvalid, opy, opx, b, lane);
+    else conv_epilogue<T, 2>(p, acc, pvalid, opy, opx, b, 0, 0, lane);
     VTI_STAMP(12);
 }
 

@@ -446,6 +446,25 @@ std::string Plan::build(const vti_desc& d) {
                 a.fused_l1 = b1.conv; a.out2 = b1.out;
                 conv_out[a.conv].buf = -1;          // the stem's output is never materialised
                 ops.erase(ops.begin() + 1);
+                // ... and the 1x1 conv that is layer 1's only consumer (model.2.cv1) runs on layer 1's register tile as a fused
+                // second stage (conv_stage2<T, 2, 2>): layer 1's 160x160x32 tensor is neither written nor read back either
+                const char* ns3 = getenv("VTI_NO_STEM_FUSE3");
+                if (!(ns3 && ns3[0] == '1') && ops.size() >= 2 && ops[1].kind == OP_CONV) {
+                    Op& s0 = ops[0];
+                    const Op& c1 = ops[1];
+                    const ConvRow& rc = convs[c1.conv];
+                    bool other = false;
+                    for (size_t j = 2; j < ops.size(); ++j)
+                        if ((ops[j].kind == OP_CONV || ops[j].kind == OP_UP2 || ops[j].kind == OP_POOL) &&
+                            (ops[j].in.buf == s0.out2.buf || (ops[j].has_res && ops[j].res.buf == s0.out2.buf))) other = true;
+                    if (rc.k == 1 && rc.s == 1 && rc.kind == 0 && rc.c1 == 32 && rc.c2 == 32 && conv_fusable(2, 2) && !c1.has_res && !c1.out_f32 &&
+                        c1.in.buf == s0.out2.buf && c1.in.coff == s0.out2.coff && c1.in.C == 32 && bufs[s0.out2.buf].C == 32 &&
+                        c1.lane == s0.lane && !other) {
+                        conv_out[s0.fused_l1].buf = -1;     // layer 1's output is not materialised
+                        s0.fused = c1.conv; s0.out2 = c1.out;
+                        ops.erase(ops.begin() + 1);
+                    }
+                }
             }
         }
     }
@@ -503,14 +522,14 @@ std::string Plan::build(const vti_desc& d) {
         if (op.kind != OP_CONV && op.kind != OP_CONV0) continue;
         const ConvRow& r = convs[op.conv];
         macs += r.macs(); fused_params += r.fused_params();
-        if (op.fused >= 0) {   // whole Cout in one wave; the per-tile kernel (2 workgroups per CU) hides the long fused epilogue better
+        if (op.fused_l1 >= 0) choose_conv_cfg(d.dtype, r, true, d.max_batch, op.cfg, 0, 0, 1, 1);   // one 16-channel n-tile: stem_l1_kernel's weight indexing
+        else if (op.fused >= 0) {   // whole Cout in one wave; the per-tile kernel (2 workgroups per CU) hides the long fused epilogue better
             const char* pf = getenv("VTI_PK_FUSED");
             choose_conv_cfg(d.dtype, r, false, d.max_batch, op.cfg, 0, 0, 1, r.c2 / 16, pf && pf[0] == '1');
         }
-        else if (op.fused_l1 >= 0) choose_conv_cfg(d.dtype, r, true, d.max_batch, op.cfg, 0, 0, 1, 1);   // one 16-channel n-tile: stem_l1_kernel's weight indexing
         else choose_conv_cfg(d.dtype, r, op.kind == OP_CONV0, d.max_batch, op.cfg);
         if (op.cfg.TH == 0) return "no launch configuration for conv " + r.name;
-        op.nat2 = (op.fused >= 0 && (op.pred_mode || op.out2_f32)) ? 1 : 0;
+        op.nat2 = (op.fused >= 0 && op.fused_l1 < 0 && (op.pred_mode || op.out2_f32)) ? 1 : 0;
         op.cfg.wpk_off = woff;
         op.cfg.bias_off = boff;
         woff += packed_conv_bytes(r, op.kind == OP_CONV0, op.cfg);
@@ -526,8 +545,13 @@ std::string Plan::build(const vti_desc& d) {
             const ConvRow& r2 = convs[op.fused];
             macs += r2.macs(); fused_params += r2.fused_params();
             op.cfg.ntiles2 = (r2.c2 + 15) / 16; op.cfg.gemm_n2 = r2.c2;
-            op.cfg.wpk_off2 = woff; op.cfg.bias_off2 = boff;
-            woff += packed_stage2_bytes(d.dtype, r2, op.cfg.NREP);
+            if (op.fused_l1 >= 0) {     // stage 2 of the stem kernel sits on layer 1's register tile (2 n-tiles); offsets 2 are layer 1's
+                op.cfg.wpk_off3 = woff; op.cfg.bias_off3 = boff;
+                woff += packed_stage2_bytes(d.dtype, r2, 2);
+            } else {
+                op.cfg.wpk_off2 = woff; op.cfg.bias_off2 = boff;
+                woff += packed_stage2_bytes(d.dtype, r2, op.cfg.NREP);
+            }
             boff += (size_t)op.cfg.ntiles2 * 16;
         }
     }

@@ -121,6 +121,7 @@ int32_t vti_conv_at(const vti_ctx* c, int32_t i, vti_conv_info* o) {
             stem_l1_tile(&o->tile_h, &o->tile_w); o->waves_n = 1; o->nrep = 2; o->lds_bytes = 0; o->fused = 1;
         } else if (op.fused == i) {     // runs inside its producer's kernel, on that kernel's geometry
             o->tile_h = op.cfg.TH; o->tile_w = op.cfg.TW; o->waves_n = 1; o->nrep = op.cfg.ntiles2;
+            if (op.fused_l1 >= 0) stem_l1_tile(&o->tile_h, &o->tile_w);
             o->lds_bytes = 0; o->fused = 1;
         }
     }
@@ -281,6 +282,18 @@ int32_t vti_forward(vti_ctx* c, const uint8_t* input, int32_t B, int32_t swap_rb
     const Plan& P = c->plan;
     hipStream_t main_st = (hipStream_t)stream;
     const int dt = P.desc.dtype;
+    static const bool list_ops = getenv("VTI_LIST_OPS") != nullptr;      // developer aid: launch order, to label a kernel trace
+    if (list_ops) {
+        int i = 0;
+        for (const Op& op : P.ops) {
+            if (op.kind == OP_FORK || op.kind == OP_JOIN) continue;
+            const bool cv = op.kind == OP_CONV || op.kind == OP_CONV0;
+            fprintf(stderr, "[op %2d] lane %d %s%s%s\n", i++, op.lane,
+                    cv ? P.convs[op.conv].name.c_str() : op.kind == OP_POOL ? "sppf_pool" : op.kind == OP_UP2 ? "upsample2x" : "decode",
+                    cv && op.fused_l1 >= 0 ? (" + " + P.convs[op.fused_l1].name).c_str() : "",
+                    cv && op.fused >= 0 ? (" + " + P.convs[op.fused].name).c_str() : "");
+        }
+    }
     for (const Op& op : P.ops) {
         hipStream_t st = (c->multi_stream && op.lane > 0) ? c->side[op.lane] : main_st;
         switch (op.kind) {
@@ -311,7 +324,15 @@ int32_t vti_forward(vti_ctx* c, const uint8_t* input, int32_t B, int32_t swap_rb
                 q.Cin = 16; q.Cout = r1.c2; q.ntiles_n = 2; q.act = 1; q.swap_rb = swap_rb ? 1 : 0;
                 q.out = buf_ptr(c, op.out2.buf, input, proto); q.out_ld = o1.C; q.out_coff = op.out2.coff;
                 q.wpk = (const char*)c->d_wpk + g.wpk_off2; q.bias = c->d_bias + g.bias_off2;     // layer 1
-                q.w2 = (const char*)c->d_wpk + g.wpk_off; q.bias2 = c->d_bias + g.bias_off;       // stem
+                q.w0 = (const char*)c->d_wpk + g.wpk_off; q.bias0 = c->d_bias + g.bias_off;       // stem
+                if (op.fused >= 0) {    // + the 1x1 conv after layer 1: layer 1 itself is not stored (out2 = that conv's view)
+                    q.out = nullptr;
+                    q.w2 = (const char*)c->d_wpk + g.wpk_off3; q.bias2 = c->d_bias + g.bias_off3;
+                    q.out2 = buf_ptr(c, op.out2.buf, input, proto);
+                    q.Cout2 = g.gemm_n2; q.ntiles2 = g.ntiles2; q.out2_ld = o1.C; q.out2_coff = op.out2.coff;
+                    q.act2 = 1; q.out2_bstride = r1.h_out * r1.w_out;
+                    q.scalar_store2 = (g.gemm_n2 % 4 || o1.C % 4 || op.out2.coff % 4) ? 1 : 0;
+                }
                 stem_l1_tile(&q.TH, &q.TW);
                 q.tiles_y = (q.Hout + q.TH - 1) / q.TH; q.tiles_x = (q.Wout + q.TW - 1) / q.TW; q.WN = 1;
                 q.scalar_store = (q.out_ld % 4 || q.out_coff % 4) ? 1 : 0;

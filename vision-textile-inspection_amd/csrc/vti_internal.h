@@ -52,6 +52,7 @@ struct ConvCfg {         // launch geometry chosen at plan time
     // fused second stage (a 1x1 conv applied to this conv's register tile), 0 tiles = none
     int ntiles2 = 0, gemm_n2 = 0;
     size_t wpk_off2 = 0, bias_off2 = 0;
+    size_t wpk_off3 = 0, bias_off3 = 0;   // stem_l1_kernel with a fused 1x1 third conv: that conv's stage-2 pack (offsets 2 = layer 1)
     // persistent LDS-DMA kernel (conv_pk.hip): TW = 20, TH = 4 * M-waves; wgpc = co-resident workgroups per CU
     int pk = 0, pk_wgpc = 1;         // pk: 1 = conv3_pk, 2 = conv1_pk (TH = compute waves along M, TW = 80)
     int pk_depth = 2, pk_wstat = 0;  // conv1_pk: stage-ring depth, weights stationary in LDS
@@ -117,6 +118,7 @@ struct ConvParams {
     unsigned in_bytes, out_bytes, res_bytes;
     // conv1_pk: channels [0, up_C) come from in2 [B, Hout/2, Wout/2, in2_ld] at (y >> 1, x >> 1): the neck's Upsample + Concat folded into the loads
     const void* in2; int in2_ld, in2_coff, up_C; unsigned in2_bytes;
+    const void* w0; const float* bias0;  // stem_l1_kernel: the stem's packed weights / bias (wpk/bias = layer 1, w2/bias2 = the fused 1x1 third conv)
     unsigned long long* stamps;          // diagnostic build only (VTI_STAMPS): 16 s_memtime slots per workgroup
 };
 

@@ -177,8 +177,11 @@ std::string pack_weights(const Plan& plan, const void* blob, size_t nbytes, std:
         }
         if (host_of[i]) {
             const ConvCfg& hc = host_of[i]->cfg;
-            pack_conv_stage2(plan.desc.dtype, r, hc.NREP, w.data(), b.data(), wpk.data() + hc.wpk_off2, bias.data() + hc.bias_off2,
-                             host_of[i]->nat2 != 0);
+            if (host_of[i]->fused_l1 >= 0)      // third conv of the stem kernel: K order of layer 1's two n-tiles
+                pack_conv_stage2(plan.desc.dtype, r, 2, w.data(), b.data(), wpk.data() + hc.wpk_off3, bias.data() + hc.bias_off3, false);
+            else
+                pack_conv_stage2(plan.desc.dtype, r, hc.NREP, w.data(), b.data(), wpk.data() + hc.wpk_off2, bias.data() + hc.bias_off2,
+                                 host_of[i]->nat2 != 0);
             continue;
         }
         const Op& op = *op_of[i];
