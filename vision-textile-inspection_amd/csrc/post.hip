@@ -468,7 +468,8 @@ __global__ __launch_bounds__(256) void mask_offsets_kernel(const int* __restrict
 
 __global__ __launch_bounds__(256) void mask_plan_kernel(const float* __restrict__ dets, const int* __restrict__ offsets, int B,
                                                         int max_det, int row, int H, int W, int capacity,
-                                                        int2* __restrict__ items, int* __restrict__ nitems) {
+                                                        int2* __restrict__ items, int* __restrict__ nitems,
+                                                        unsigned* __restrict__ csplit) {
     const int slot = blockIdx.x * 256 + threadIdx.x;
     const int total = min(offsets[B], capacity);
     if (slot >= total) return;
@@ -477,6 +478,23 @@ __global__ __launch_bounds__(256) void mask_plan_kernel(const float* __restrict_
     while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (offsets[mid] <= slot) lo = mid; else hi = mid; }
     const int inst = slot - offsets[lo];
     const float* d = dets + ((size_t)lo * max_det + inst) * row;
+    // fp16 prototypes, 32 coefficients: each fp32 coefficient c is split as c = h + l with h = half(c), l = half(c - h)
+    // (exact to 2^-22 |c|), packed in channel pairs, so the tile kernel's dots run as v_dot2_f32_f16 (products exact, fp32
+    // accumulation) at a quarter of the instructions of convert + fma.  Coefficients outside half range keep the fp32 path.
+    unsigned big = 0;
+    if (csplit && row == 6 + 32) {
+        unsigned* cs = csplit + (size_t)slot * 32;
+        for (int k = 0; k < 16; ++k) {
+            const float c0 = d[6 + 2 * k], c1 = d[6 + 2 * k + 1];
+            if (!(fabsf(c0) < 3.0e4f) || !(fabsf(c1) < 3.0e4f)) big = 1u;
+            const half_t h0 = (half_t)c0, h1 = (half_t)c1;
+            const half_t l0 = (half_t)(c0 - (float)h0), l1 = (half_t)(c1 - (float)h1);
+            cs[k] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+            cs[16 + k] = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+        }
+    } else {
+        big = 1u;
+    }
     // a tile can be non-zero only if one of its bilinear taps lies inside the box (in 1/4-res
     // pixels); expand the box by 2 low-res pixels (= 8 output px) to be safe on every side
     const float x1 = d[0] - 8.f, y1 = d[1] - 8.f, x2 = d[2] + 8.f, y2 = d[3] + 8.f;
@@ -486,31 +504,51 @@ __global__ __launch_bounds__(256) void mask_plan_kernel(const float* __restrict_
     if (cnt == 0) return;
     int base = atomicAdd(nitems, cnt);
     for (int ty = ty0; ty <= ty1; ++ty)
-        for (int tx = tx0; tx <= tx1; ++tx) items[base++] = make_int2((slot * tiles_y + ty) * tiles_x + tx, (lo << 16) | inst);
+        for (int tx = tx0; tx <= tx1; ++tx) items[base++] = make_int2((slot << 12) | (ty << 6) | tx, (int)((big << 31) | ((unsigned)lo << 16) | (unsigned)inst));   // tiles < 64 per side
 }
+
+#ifdef VTI_STAMPS   // diagnostic build only: cycles per phase of masks_kernel, summed over the items of wave 0 of every block
+__device__ unsigned long long g_mask_acc[8];
+#define MASK_T(i) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
+                       macc[i] += t_ - mprev; mprev = t_; } while (0)
+#else
+#define MASK_T(i) do { } while (0)
+#endif
 
 template <typename T, int NM>      // NM = compile-time coefficient count (32), 0 = use the runtime nm
 __global__ __launch_bounds__(256) void masks_kernel(const float* __restrict__ dets, const int* __restrict__ offsets,
                                                     const T* __restrict__ proto, int B, int max_det, int nm, int Hp,
                                                     int Wp, int H, int W, int mode, int packing,
                                                     uint8_t* __restrict__ masks, const int2* __restrict__ items,
-                                                    const int* __restrict__ nitems) {
+                                                    const int* __restrict__ nitems, const unsigned* __restrict__ csplit) {
     __shared__ float coef[64];
     __shared__ float low[ML][ML + 1];
     const int tid = threadIdx.x;
-    const int tiles_x = (W + MT - 1) / MT, tiles_y = (H + MT - 1) / MT;
     const int n = *nitems;
+    int2 itm_next = blockIdx.x < n ? items[blockIdx.x] : make_int2(0, 0);
+#ifdef VTI_STAMPS
+    unsigned long long macc[6] = {0, 0, 0, 0, 0, 0}, mprev, mitems = 0;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(mprev)::"memory");
+#endif
     for (int it = blockIdx.x; it < n; it += gridDim.x) {
-        const int2 itm = items[it];
+        const int2 itm = itm_next;
+        {   // the next item's record is fetched a whole item ahead (clamped index: nothing consumes it in this iteration)
+            const int itn = it + (int)gridDim.x;
+            itm_next = items[itn < n ? itn : it];
+        }
         const int item = __builtin_amdgcn_readfirstlane(itm.x);          // block-uniform: keep it scalar
         const int code = __builtin_amdgcn_readfirstlane(itm.y);
-        const int tx = item % tiles_x, ty = (item / tiles_x) % tiles_y, slot = item / (tiles_x * tiles_y);
-        const int b = code >> 16, inst = code & 0xffff;
+        const int tx = item & 63, ty = (item >> 6) & 63, slot = item >> 12;      // packed by mask_plan_kernel: no divisions here
+        const int b = (code >> 16) & 0x7fff, inst = code & 0xffff;
+        const bool split_ok = code >= 0;  // bit 31: a coefficient outside half range (or no split table) -> fp32 dots
+        MASK_T(0);                        // item record decoded
         __syncthreads();                  // previous iteration is done with the shared tiles
+        MASK_T(1);
         const int y0 = ty * MT, x0 = tx * MT;
         const int row = 6 + nm;
         const float* d = dets + ((size_t)b * max_det + inst) * row;
-        if (tid < nm) coef[tid] = d[6 + tid];
+        const bool fast = NM == 32 && sizeof(T) == 2 && split_ok;        // block-uniform
+        if (!fast && tid < nm) coef[tid] = d[6 + tid];
 
         // torch: area_pixel_compute_scale<float>(in, out) = (float)in / out ; src = scale*(dst+0.5)-0.5, clamped at 0
         const float sh = (float)Hp / (float)H, sw = (float)Wp / (float)W;
@@ -520,8 +558,62 @@ __global__ __launch_bounds__(256) void masks_kernel(const float* __restrict__ de
         // crop box in prototype pixels: boxes * (mw/iw) etc. in fp32 (torch multiplies an f32 tensor by a python float)
         const float wr = (float)((double)Wp / (double)W), hr = (float)((double)Hp / (double)H);
         const float bx1 = d[0] * wr, by1 = d[1] * hr, bx2 = d[2] * wr, by2 = d[3] * hr;
+        if constexpr (NM == 32 && sizeof(T) == 2) {
+            if (fast) {
+                // fp16 prototypes, split coefficients.  Two lanes share a low-res point (16 channels = 32 contiguous bytes each),
+                // so a wave instruction reads 2 KiB of contiguous prototype rows instead of 64 scattered 16-byte pieces (the
+                // per-point layout kept the CU's L1 at one access per cycle for the whole kernel: TCP_TOTAL_ACCESSES ~= cycles).
+                // All loads of the item are issued together, unconditionally and from clamped addresses, BEFORE anything is
+                // consumed (hipcc waits for a load that sits inside a branch; see conv.hip, stem_l1_kernel).
+                typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                constexpr int RP = ML * 2, NP = ML * RP, NRD = (NP + 255) / 256;      // half-points per row / per tile, rounds
+                const int half = tid & 1;                                 // == idx & 1 in every round (RP and 256 are even)
+                const uint4* cs4 = (const uint4*)(csplit + (size_t)slot * 32);
+                const uint4 chv[2] = {cs4[half * 2], cs4[half * 2 + 1]}, clv[2] = {cs4[4 + half * 2], cs4[4 + half * 2 + 1]};
+                uint4 pv[NRD][2];
+                bool inb[NRD], wr[NRD];
+                int la[NRD];
+#pragma unroll
+                for (int u = 0; u < NRD; ++u) {
+                    const int idx = tid + 256 * u;
+                    const bool live = idx < NP;
+                    const int ic = live ? idx : 0;
+                    const int r = ic / RP, q = ic - r * RP, c = q >> 1;
+                    la[u] = r * (ML + 1) + c;
+                    wr[u] = live && half == 0;
+                    const int py = ly0 + r, px = lx0 + c;
+                    const float fr = (float)py, fc = (float)px;
+                    inb[u] = py < Hp && px < Wp && fc >= bx1 && fc < bx2 && fr >= by1 && fr < by2;
+                    const int pyc = py < Hp ? py : Hp - 1, pxc = px < Wp ? px : Wp - 1;
+                    const uint4* pp = (const uint4*)(proto + ((size_t)(b * Hp + pyc) * Wp + pxc) * 32 + half * 16);
+                    pv[u][0] = pp[0]; pv[u][1] = pp[1];
+                }
+                MASK_T(2);                // box loaded, prototype loads issued
+#pragma unroll
+                for (int u = 0; u < NRD; ++u) {
+                    float acc = 0.f, acc_l = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const unsigned w[4] = {pv[u][k].x, pv[u][k].y, pv[u][k].z, pv[u][k].w};
+                        const unsigned ch[4] = {chv[k].x, chv[k].y, chv[k].z, chv[k].w}, cl[4] = {clv[k].x, clv[k].y, clv[k].z, clv[k].w};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const h2 x = __builtin_bit_cast(h2, w[j]);
+                            acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, ch[j]), x, acc, false);
+                            acc_l = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, cl[j]), x, acc_l, false);
+                        }
+                    }
+                    acc += acc_l;
+                    // the other half of the point sits in the neighbouring lane (quad_perm [1,0,3,2])
+                    acc += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, acc), 0xB1, 0xF, 0xF, true));
+                    float v = mode == VTI_MASK_SIGMOID ? 1.0f / (1.0f + expf(-acc)) : acc;
+                    v = inb[u] ? v : 0.f;
+                    if (wr[u]) (&low[0][0])[la[u]] = v;
+                }
+            }
+        }
+        if (!fast) {
         __syncthreads();
-
         for (int e = tid; e < ML * ML; e += 256) {
             const int r = e / ML, c = e - r * ML;
             const int py = ly0 + r, px = lx0 + c;
@@ -555,76 +647,85 @@ __global__ __launch_bounds__(256) void masks_kernel(const float* __restrict__ de
             }
             low[r][c] = v;
         }
+        }
+        MASK_T(3);                        // dots done, low-res tile written
         __syncthreads();
+        MASK_T(4);
 
         const float thr = mode == VTI_MASK_SIGMOID ? 0.5f : 0.0f;
-        const int ry = tid >> 2, seg = (tid & 3) * 16;
-        const int y = y0 + ry;
-        if (y >= H) continue;
-        // F.interpolate(bilinear, align_corners=False) at the fixed 1/4 scale: src = 0.25*(dst+0.5)-0.5 clamped
-        // at 0, so for dst >= 2 the source index is (dst-2)>>2 with fraction {0.125,0.375,0.625,0.875}[(dst-2)&3]
-        // and for dst < 2 it is index 0, fraction 0 (all exact in fp32: the same values the generic formula
-        // gives).  A thread's 16 consecutive output pixels touch at most 6 low-res columns of 2 rows.
-        const int iy = y >= 2 ? (y - 2) >> 2 : 0;
-        const float ly1 = y >= 2 ? 0.125f + 0.25f * (float)((y - 2) & 3) : 0.0f, lyw0 = 1.0f - ly1;
-        const int iy1 = iy + (iy < Hp - 1 ? 1 : 0);
-        const int xs = x0 + seg;                                   // multiple of 16
-        const int cb = xs >= 2 ? (xs - 2) >> 2 : 0;                // first low-res column this thread needs
-        float r0[6], r1[6];
+        // F.interpolate(bilinear, align_corners=False) at the fixed 1/4 scale: src = 0.25*(dst+0.5)-0.5 clamped at 0, so for
+        // dst >= 2 the source index is (dst-2)>>2 with fraction {0.125,0.375,0.625,0.875}[(dst-2)&3] and for dst < 2 it is
+        // index 0, fraction 0 (all exact in fp32: the same values the generic formula gives).
+        // A wave owns 16 rows of the tile and a LANE IS A COLUMN: its horizontal taps and weights are fixed, so the horizontal
+        // blend is done once per low-res row (6 per wave), a pixel then costs one vertical blend (torch's order: horizontal
+        // first) and the 64-lane compare mask of a row IS that row's 8 output bytes -- 3 VALU instructions per 64 pixels.
+        const int wv = tid >> 6, ln = tid & 63;
+        const int yw = __builtin_amdgcn_readfirstlane(y0 + 16 * wv);      // first row of this wave
+        if (yw >= H) continue;
+        const int xg = x0 + ln;
+        int k0 = xg >= 2 ? (xg - 2) >> 2 : 0;
+        k0 = k0 < Wp - 1 ? k0 : Wp - 1;                                   // columns past W (partial tile) are masked below
+        const int k1 = k0 + (k0 < Wp - 1 ? 1 : 0);
+        const float lx1 = xg >= 2 ? 0.125f + 0.25f * (float)((xg - 2) & 3) : 0.0f, lxw0 = 1.0f - lx1;
+        const int rb = (yw >> 2) - 1;                                     // low-res row of (yw - 2) >> 2
+        float hb[6];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            int cc = cb + k;
-            cc = cc < Wp - 1 ? cc : Wp - 1;                        // == min(ix + 1, Wp - 1) for the second tap
-            r0[k] = low[iy - ly0][cc - lx0];
-            r1[k] = low[iy1 - ly0][cc - lx0];
+        for (int j = 0; j < 6; ++j) {
+            int rr = rb + j;
+            rr = rr < 0 ? 0 : (rr > Hp - 1 ? Hp - 1 : rr);                // == min(iy + 1, Hp - 1) for the lower tap
+            rr -= ly0;
+            hb[j] = low[rr][k0 - lx0] * lxw0 + low[rr][k1 - lx0] * lx1;
         }
-        // bilinear weights are separable and the interpolation is linear in its four taps: blend the two low-res rows first
-        // (6 columns per thread), then 16 pixels x one horizontal blend -- 66 instead of 144 flops per thread.  (torch blends
-        // horizontally first; the two orders differ by fp32 rounding only, i.e. at pixels whose value is within ~1e-7 of the
-        // threshold.  The mask gate is IoU >= 0.999 against the CPU reference, tests/test_gpu_postproc.py.)
-        float cv[6];
+        const int valid = W - x0;                                         // 32 or >= 64 (W is a multiple of 32)
+        const unsigned long long cmask = valid >= 64 ? ~0ull : ((1ull << valid) - 1ull);
+        unsigned lo = 0u, hi = 0u;
+        auto rows16 = [&](auto bytes) {                                   // two unrolled variants: no per-row branch on the packing
+            constexpr bool BYTES = decltype(bytes)::value;
+            unsigned l_ = 0u, h_ = 0u;
 #pragma unroll
-        for (int k = 0; k < 6; ++k) cv[k] = r0[k] * lyw0 + r1[k] * ly1;
-        unsigned bits = 0;
-        // two fully unrolled variants so every register-array index is a compile-time constant
-        auto px16 = [&](auto first) {
-            constexpr bool FIRST = decltype(first)::value;      // xs == 0: pixels 0,1 clamp to column 0
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int k0 = FIRST ? (j >= 2 ? (j - 2) >> 2 : 0) : (j + 2) >> 2;
-                const float lx1 = FIRST ? (j >= 2 ? 0.125f + 0.25f * (float)((j - 2) & 3) : 0.0f)
-                                        : 0.125f + 0.25f * (float)((j + 2) & 3);
-                const float lxw0 = 1.0f - lx1;
-                const bool on = xs + j < W && (cv[k0] * lxw0 + cv[k0 + 1] * lx1) > thr;
-                bits |= (on ? 1u : 0u) << j;
+            for (int r = 0; r < 16; ++r) {
+                constexpr float FR[4] = {0.125f, 0.375f, 0.625f, 0.875f};
+                const int j = (r + 2) >> 2;                               // low-res row of output row yw + r, relative to rb
+                float w1 = FR[(r + 2) & 3];
+                if (r < 2 && yw == 0) w1 = 0.0f;                          // rows 0, 1 of the image clamp to source row 0
+                const float v = hb[j] * (1.0f - w1) + hb[j + 1] * w1;
+                if constexpr (BYTES) {
+                    if (xg < W && yw + r < H) masks[((size_t)slot * H + yw + r) * W + xg] = v > thr ? (uint8_t)1 : (uint8_t)0;
+                } else {
+                    const unsigned long long m = __builtin_amdgcn_ballot_w64(v > thr);
+                    const unsigned mlo = (unsigned)m, mhi = (unsigned)(m >> 32);      // wave-uniform (SGPRs)
+                    // the compare writes VCC and v_writelane reads it as an SGPR operand: the hardware needs wait states in
+                    // between and the compiler's hazard recogniser does not look inside inline asm (seen as wrong bits in
+                    // exactly the rows whose compare sat next to its writelane)
+                    asm("s_nop 4\n\tv_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4"
+                        : "+v"(l_), "+v"(h_) : "s"(mlo), "s"(mhi), "n"(r));
+                }
             }
+            lo = l_; hi = h_;
         };
-        if (xs == 0) px16(std::true_type{}); else px16(std::false_type{});
-        unsigned wrd[4];                      // 16 mask bytes (0/1), little endian
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const unsigned n4 = (bits >> (4 * k)) & 0xfu;
-            wrd[k] = (n4 & 1u) | ((n4 & 2u) << 7) | ((n4 & 4u) << 14) | ((n4 & 8u) << 21);
+        if (packing == VTI_PACK_U8) rows16(std::true_type{}); else rows16(std::false_type{});
+        lo &= (unsigned)cmask; hi &= (unsigned)(cmask >> 32);            // columns past W (partial tile)
+        if (packing != VTI_PACK_U8 && ln < 16 && yw + ln < H) {           // lane r stores row r: 8 (4) bytes of bits
+            const int wb = W >> 3;
+            unsigned* o = (unsigned*)(masks + ((size_t)slot * H + yw + ln) * wb + (x0 >> 3));     // 4-byte aligned (W % 32 == 0)
+            o[0] = lo;
+            if (valid >= 64) o[1] = hi;
         }
-        if (packing == VTI_PACK_U8) {
-            uint8_t* o = masks + ((size_t)slot * H + y) * W + x0 + seg;
-            if (x0 + seg + 16 <= W && (W & 15) == 0) {
-                *(uint4*)o = make_uint4(wrd[0], wrd[1], wrd[2], wrd[3]);
-            } else {
-                for (int j = 0; j < 16 && x0 + seg + j < W; ++j) o[j] = (uint8_t)((bits >> j) & 1u);
-            }
-        } else {
-            const int wb = W >> 3;   // W is a multiple of 32
-            uint8_t* o = masks + ((size_t)slot * H + y) * wb + ((x0 + seg) >> 3);
-            if (x0 + seg < W) o[0] = (uint8_t)(bits & 0xff);
-            if (x0 + seg + 8 < W) o[1] = (uint8_t)(bits >> 8);
-        }
+#ifdef VTI_STAMPS
+        MASK_T(5); ++mitems;
+#endif
     }
+#ifdef VTI_STAMPS
+    if (tid == 0) {
+        for (int i = 0; i < 6; ++i) atomicAdd(&g_mask_acc[i], macc[i]);
+        atomicAdd(&g_mask_acc[6], mitems);
+    }
+#endif
 }
 
 size_t masks_workspace_bytes(int capacity, int H, int W) {
     const size_t tiles = (size_t)((H + MT - 1) / MT) * ((W + MT - 1) / MT);
-    return 256 + ((((size_t)capacity * tiles * 8) + 255) & ~(size_t)255);
+    return 256 + ((((size_t)capacity * tiles * 8) + 255) & ~(size_t)255) + (size_t)capacity * 128;   // nitems | items | split coefficients
 }
 
 hipError_t launch_masks(int dtype, const float* dets, const int* counts, const void* proto, int B, int max_det, int nm,
@@ -634,20 +735,35 @@ hipError_t launch_masks(int dtype, const float* dets, const int* counts, const v
     if (Hp * 4 != H || Wp * 4 != W || nm > 64) return hipErrorInvalidValue;   // tile geometry assumes stride-4 prototypes
     int* nitems = (int*)ws;
     int2* items = (int2*)((char*)ws + 256);
-    if (max_det > 65535) return hipErrorInvalidValue;
+    const size_t tiles = (size_t)((H + MT - 1) / MT) * ((W + MT - 1) / MT);
+    unsigned* csplit = (dtype == VTI_F16 && nm == 32) ? (unsigned*)((char*)ws + 256 + ((((size_t)capacity * tiles * 8) + 255) & ~(size_t)255)) : nullptr;
+    if (max_det > 65535 || B > 32767 || H > 64 * MT || W > 64 * MT || capacity > (1 << 19)) return hipErrorInvalidValue;    // item record fields
     hipLaunchKernelGGL(mask_offsets_kernel, dim3(1), dim3(256), (size_t)(B + 1) * sizeof(int), st, counts, B, max_det, offsets, nitems);
     if (capacity <= 0) return hipGetLastError();
     hipLaunchKernelGGL(mask_plan_kernel, dim3((capacity + 255) / 256), dim3(256), 0, st, dets, offsets, B, max_det, 6 + nm, H, W,
-                       capacity, items, nitems);
+                       capacity, items, nitems, csplit);
     const size_t out_bytes = (size_t)capacity * H * (packing == VTI_PACK_U8 ? W : W / 8);
     hipError_t e = hipMemsetAsync(masks, 0, out_bytes, st);
     if (e != hipSuccess) return e;
     const int grid = 256 * 8;     // persistent blocks walk the work list
 #define VTI_MASKS(TT, NMV) hipLaunchKernelGGL((masks_kernel<TT, NMV>), dim3(grid), dim3(256), 0, st, dets, offsets, (const TT*)proto, \
-                                                B, max_det, nm, Hp, Wp, H, W, mode, packing, masks, items, nitems)
+                                                B, max_det, nm, Hp, Wp, H, W, mode, packing, masks, items, nitems, csplit)
     if (dtype == VTI_F16) { if (nm == 32) VTI_MASKS(half_t, 32); else VTI_MASKS(half_t, 0); }
     else { if (nm == 32) VTI_MASKS(float, 32); else VTI_MASKS(float, 0); }
 #undef VTI_MASKS
+#ifdef VTI_STAMPS
+    {
+        (void)hipStreamSynchronize(st);
+        static int calls = 0;
+        if (++calls == 3) {
+            unsigned long long h[8];
+            (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_mask_acc), sizeof h);
+            const char* nm_[6] = {"decode item", "barrier 1", "box + issue loads", "dots -> LDS", "barrier 2", "upsample + store"};
+            fprintf(stderr, "[mask stamps] %llu items over %d calls (wave 0 of each block; 100 MHz ticks per item)\n", h[6], calls);
+            for (int i = 0; i < 6; ++i) fprintf(stderr, "[mask stamps] %-18s %8.1f\n", nm_[i], (double)h[i] / (double)h[6]);
+        }
+    }
+#endif
     return hipGetLastError();
 }
 
