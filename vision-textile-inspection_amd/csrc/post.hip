@@ -291,12 +291,18 @@ __device__ __forceinline__ void nms_body(const float* __restrict__ P, int A, int
             unsigned long long alive = __ballot(alive_l);
             unsigned long long keptmask = 0;
             int k_ = kept;
+            // lane l holds row l of the matrix; the walk fetches row i with v_readlane (i is wave-uniform) instead of a
+            // dependent LDS read per kept box (~100 cycles each, 64 in a row: a third of the greedy phase on crowded frames)
+            const unsigned long long myrow = s_rows[tid];
+            const int row_lo = (int)(unsigned)myrow, row_hi = (int)(unsigned)(myrow >> 32);
             while (alive && k_ < max_det) {
                 const int i = __ffsll((long long)alive) - 1;
                 keptmask |= 1ull << i;
                 if (tid == 0) keep[k_] = base + i;
                 ++k_;
-                alive &= ~(s_rows[i] | (1ull << i));
+                const unsigned long long ri = (unsigned long long)(unsigned)__builtin_amdgcn_readlane(row_lo, i) |
+                                              ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(row_hi, i) << 32);
+                alive &= ~(ri | (1ull << i));
             }
             if (tid == 0) { s_keptmask = keptmask; s_kept = k_; }
         }
