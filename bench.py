@@ -264,7 +264,7 @@ def main():
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / MFMA_PEAK_TFLOPS, 5), "traffic": traffic,
                          "traffic_note": "HBM bytes per forward (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes, profiles/r01_hbm_traffic.json); algorithmic unfused activation bytes = 91.6 MB/frame",
-                         "kernel": f"vti conv family: conv3_pk / conv1_pk (persistent LDS-DMA 3x3 / 1x1) + conv_kernel (fused towers, stride 2) + stem_l1_kernel ({eng.num_launches} launches per forward incl. the SPPF pool; 76 convs, 11 fused into their producer, decode fused into the box towers)",
+                         "kernel": f"vti conv family: conv3_pk / conv1_pk (persistent LDS-DMA 3x3 / 1x1) + conv_kernel (fused towers, stride 2) + stem_l1_kernel ({eng.num_launches} launches per forward incl. the SPPF pool; {len(eng.conv_table())} convs, {sum(1 for t in eng.conv_table() if t['fused'])} fused into their producer's kernel, decode fused into the box towers)",
                          "flop_per_launch": flops_per_forward, "avg_ms": round(fwd_ms, 4),
                          "isolated": {"avg_ms": round(iso_ms, 4), "achieved": round(flops_per_forward / (iso_ms * 1e-3) / 1e12, 2),
                                       "frac": round(flops_per_forward / (iso_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 5),
