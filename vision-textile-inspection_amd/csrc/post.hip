@@ -531,16 +531,23 @@ __global__ __launch_bounds__(256) void masks_kernel(const float* __restrict__ de
     __shared__ float low[ML][ML + 1];
     const int tid = threadIdx.x;
     const int n = *nitems;
-    int2 itm_next = blockIdx.x < n ? items[blockIdx.x] : make_int2(0, 0);
+    // XCD x (= blockIdx & 7: workgroups are dealt round-robin to the 8 XCDs) walks its own contiguous eighth of the work list,
+    // round-robin over its workgroups: at any time an XCD works on ~1 frame, whose prototypes are fetched into ONE L2 instead
+    // of eight, and the 8-byte row pieces that share a 128-byte output line are written through one L2.  (A contiguous run
+    // per workgroup instead spreads the chip over all 64 frames at once: 333 -> 363 us.)
+    const int nx = (int)gridDim.x >> 3, xcd = (int)blockIdx.x & 7, jx = (int)blockIdx.x >> 3;
+    const int per = (n + 7) >> 3;
+    const int it0 = xcd * per + jx, it1 = min(n, (xcd + 1) * per);
+    int2 itm_next = it0 < it1 ? items[it0] : make_int2(0, 0);
 #ifdef VTI_STAMPS
     unsigned long long macc[6] = {0, 0, 0, 0, 0, 0}, mprev, mitems = 0;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(mprev)::"memory");
 #endif
-    for (int it = blockIdx.x; it < n; it += gridDim.x) {
+    for (int it = it0; it < it1; it += nx) {
         const int2 itm = itm_next;
         {   // the next item's record is fetched a whole item ahead (clamped index: nothing consumes it in this iteration)
-            const int itn = it + (int)gridDim.x;
-            itm_next = items[itn < n ? itn : it];
+            const int itn = it + nx;
+            itm_next = items[itn < it1 ? itn : it];
         }
         const int item = __builtin_amdgcn_readfirstlane(itm.x);          // block-uniform: keep it scalar
         const int code = __builtin_amdgcn_readfirstlane(itm.y);
