@@ -337,26 +337,36 @@ __device__ __forceinline__ void nms_body(const float* __restrict__ P, int A, int
     __syncthreads();
     const int row = 6 + nm;
     const unsigned row_magic = (unsigned)((0x100000000ull + (unsigned)row - 1) / (unsigned)row);
-    auto elem = [&](int e) -> float {          // element e of the kept rows: (k, f) = (e / row, e % row)
-        const int k = (int)__umulhi((unsigned)e, row_magic), f = e - k * row;
-        const int a = kid[k], j = kcls[k];
-        if (f < 4) {
-            const float c_ = P[(size_t)a * (4 + nc + nm) + (f & 1)], s_ = P[(size_t)a * (4 + nc + nm) + 2 + (f & 1)];   // centre, size of this axis
-            const float d_ = s_ / 2.0f;
-            return f < 2 ? c_ - d_ : c_ + d_;
-        }
-        if (f == 4) return P[(size_t)a * (4 + nc + nm) + 4 + j];
-        if (f == 5) return (float)j;
-        return P[(size_t)a * (4 + nc + nm) + 4 + nc + (f - 6)];
-    };
+    // element e of the kept rows: (k, f) = (e / row, e % row).  Every element issues the same two UNCONDITIONAL loads (centre and
+    // size of its axis for the box fields, the same word twice otherwise) and a thread issues all of its group before using
+    // any: a load behind a data-dependent branch makes hipcc wait for it on the spot (one DRAM round trip per element: 39 k
+    // cycles for 217 rows, the crowded frame that sets this kernel's duration).
     const int nel = kept * row, ntot = max_det * row;
-    for (int e0 = tid; e0 < nel; e0 += 4 * NMS_THREADS) {      // 4 independent gathers in flight per thread
-        float v[4];
+    const int no_ = 4 + nc + nm;
+    constexpr int OU = 8;
+    for (int e0 = tid; e0 < nel; e0 += OU * NMS_THREADS) {
+        float x1[OU], x2[OU];
+        int fj[OU];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = e0 + u * NMS_THREADS < nel ? elem(e0 + u * NMS_THREADS) : 0.f;
+        for (int u = 0; u < OU; ++u) {
+            const int e = e0 + u * NMS_THREADS;
+            const int ec = e < nel ? e : 0;
+            const int k = (int)__umulhi((unsigned)ec, row_magic), f = ec - k * row;
+            const int a = kid[k], j = kcls[k];
+            const int off1 = f < 4 ? (f & 1) : f == 4 ? 4 + j : f == 5 ? 0 : 4 + nc + (f - 6);
+            const int off2 = f < 4 ? 2 + (f & 1) : off1;
+            const float* Pa = P + (size_t)a * no_;
+            x1[u] = Pa[off1]; x2[u] = Pa[off2];
+            fj[u] = (f << 16) | j;
+        }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (e0 + u * NMS_THREADS < nel) D[e0 + u * NMS_THREADS] = v[u];
+        for (int u = 0; u < OU; ++u) {
+            const int e = e0 + u * NMS_THREADS;
+            const int f = fj[u] >> 16, j = fj[u] & 0xffff;
+            const float d_ = x2[u] / 2.0f;
+            const float v = f < 2 ? x1[u] - d_ : f < 4 ? x1[u] + d_ : f == 5 ? (float)j : x1[u];
+            if (e < nel) D[e] = v;
+        }
     }
     for (int e = nel + tid; e < ntot; e += NMS_THREADS) D[e] = 0.f;
     __syncthreads();
