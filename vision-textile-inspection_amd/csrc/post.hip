@@ -255,7 +255,7 @@ __device__ __forceinline__ void nms_body(const float* __restrict__ P, int A, int
     //   A. all threads: bit (i, j) of the 64x64 intra-block matrix = "i suppresses j" (j > i)
     //   B. wave 0: walk the block's still-alive candidates in order with 64-bit masks
     //   C. all threads: the block's kept boxes suppress every later candidate
-    __shared__ unsigned long long s_rows[64], s_keptmask;
+    __shared__ unsigned long long s_rows[64];
     __shared__ int s_kept;
     auto iou_gt = [&](const f32x4& bi, float ai, const f32x4& bj, float aj) -> bool {
         const float xx1 = fmaxf(bi[0], bj[0]), yy1 = fmaxf(bi[1], bj[1]);
@@ -278,9 +278,17 @@ __device__ __forceinline__ void nms_body(const float* __restrict__ P, int A, int
             const f32x4 bi = boxes[base + i];
             const float ai = area[base + i];
             unsigned long long m = 0;
+            f32x4 bj8[8];
+            float aj8[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {          // the 8 operands first (clamped index), then the tests: no wait per pair
+                const int jc = jg + k < cnt ? jg + k : cnt - 1;
+                bj8[k] = boxes[base + jc]; aj8[k] = area[base + jc];
+            }
+#pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const int j = jg + k;
-                if (j > i && j < cnt && iou_gt(bi, ai, boxes[base + j], area[base + j])) m |= 1ull << j;
+                if (j > i && j < cnt && iou_gt(bi, ai, bj8[k], aj8[k])) m |= 1ull << j;
             }
             if (m) atomicOr(&s_rows[i], m);
         }
@@ -289,7 +297,6 @@ __device__ __forceinline__ void nms_body(const float* __restrict__ P, int A, int
         if (tid < 64) {
             const bool alive_l = tid < cnt && !suppressed[base + tid];
             unsigned long long alive = __ballot(alive_l);
-            unsigned long long keptmask = 0;
             int k_ = kept;
             // lane l holds row l of the matrix; the walk fetches row i with v_readlane (i is wave-uniform) instead of a
             // dependent LDS read per kept box (~100 cycles each, 64 in a row: a third of the greedy phase on crowded frames)
@@ -297,30 +304,38 @@ __device__ __forceinline__ void nms_body(const float* __restrict__ P, int A, int
             const int row_lo = (int)(unsigned)myrow, row_hi = (int)(unsigned)(myrow >> 32);
             while (alive && k_ < max_det) {
                 const int i = __ffsll((long long)alive) - 1;
-                keptmask |= 1ull << i;
                 if (tid == 0) keep[k_] = base + i;
                 ++k_;
                 const unsigned long long ri = (unsigned long long)(unsigned)__builtin_amdgcn_readlane(row_lo, i) |
                                               ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(row_hi, i) << 32);
                 alive &= ~(ri | (1ull << i));
             }
-            if (tid == 0) { s_keptmask = keptmask; s_kept = k_; }
+            if (tid == 0) s_kept = k_;
         }
         __syncthreads();
+        const int kept0 = kept;           // keep[kept0 .. kept) are this block's kept candidates, in order
         kept = s_kept;
-        // C: later candidates vs this block's kept boxes
-        const unsigned long long km = s_keptmask;
+        // C: later candidates vs this block's kept boxes, four at a time (operands of a group loaded together; a candidate
+        // is suppressed iff ANY kept box of the block overlaps it, so the order of the tests does not matter)
         if (kept < max_det) {
+            const int nk = kept - kept0;
             for (int j = base + 64 + tid; j < n; j += NMS_THREADS) {
                 if (suppressed[j]) continue;
                 const f32x4 bj = boxes[j];
                 const float aj = area[j];
-                unsigned long long r = km;
-                while (r) {
-                    const int i = __ffsll((long long)r) - 1;
-                    r &= r - 1;
-                    if (iou_gt(boxes[base + i], area[base + i], bj, aj)) { suppressed[j] = 1; break; }
+                bool sup = false;
+                for (int t = 0; t < nk && !sup; t += 4) {
+                    int ii[4];
+                    f32x4 bk[4];
+                    float ak[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) ii[u] = keep[kept0 + (t + u < nk ? t + u : nk - 1)];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { bk[u] = boxes[ii[u]]; ak[u] = area[ii[u]]; }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) sup = sup | iou_gt(bk[u], ak[u], bj, aj);
                 }
+                if (sup) suppressed[j] = 1;
             }
         }
         __syncthreads();
