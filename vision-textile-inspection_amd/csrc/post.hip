@@ -547,7 +547,7 @@ __device__ unsigned long long g_mask_acc[8];
 #endif
 
 template <typename T, int NM>      // NM = compile-time coefficient count (32), 0 = use the runtime nm
-__global__ __launch_bounds__(256) void masks_kernel(const float* __restrict__ dets, const int* __restrict__ offsets,
+__global__ __launch_bounds__(256, 6) void masks_kernel(const float* __restrict__ dets, const int* __restrict__ offsets,
                                                     const T* __restrict__ proto, int B, int max_det, int nm, int Hp,
                                                     int Wp, int H, int W, int mode, int packing,
                                                     uint8_t* __restrict__ masks, const int2* __restrict__ items,
@@ -783,7 +783,18 @@ hipError_t launch_masks(int dtype, const float* dets, const int* counts, const v
     const size_t out_bytes = (size_t)capacity * H * (packing == VTI_PACK_U8 ? W : W / 8);
     hipError_t e = hipMemsetAsync(masks, 0, out_bytes, st);
     if (e != hipSuccess) return e;
-    const int grid = 256 * 8;     // persistent blocks walk the work list
+    // persistent blocks walk the work list: exactly as many as are resident at once (a second round of late blocks would run
+    // on a mostly empty chip), a multiple of 8 for the per-XCD partition
+    static int per_cu[4] = {0, 0, 0, 0};
+    const int kidx = (dtype == VTI_F16 ? 0 : 2) + (nm == 32 ? 0 : 1);
+    if (!per_cu[kidx]) {
+        int nb = 0;
+        const void* fn = dtype == VTI_F16 ? (nm == 32 ? (const void*)masks_kernel<half_t, 32> : (const void*)masks_kernel<half_t, 0>)
+                                          : (nm == 32 ? (const void*)masks_kernel<float, 32> : (const void*)masks_kernel<float, 0>);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 256, 0) != hipSuccess || nb < 1) nb = 4;
+        per_cu[kidx] = nb > 8 ? 8 : nb;
+    }
+    const int grid = 256 * per_cu[kidx];
 #define VTI_MASKS(TT, NMV) hipLaunchKernelGGL((masks_kernel<TT, NMV>), dim3(grid), dim3(256), 0, st, dets, offsets, (const TT*)proto, \
                                                 B, max_det, nm, Hp, Wp, H, W, mode, packing, masks, items, nitems, csplit)
     if (dtype == VTI_F16) { if (nm == 32) VTI_MASKS(half_t, 32); else VTI_MASKS(half_t, 0); }
