@@ -122,7 +122,8 @@ int32_t vti_forward(vti_ctx* ctx, const uint8_t* dev_input, int32_t B, int32_t s
 /* U6 non_max_suppression (class-aware unless agnostic), torchvision.ops.nms semantics. */
 int32_t vti_nms(vti_ctx* ctx, const float* dev_pred, int32_t B, float conf, double iou,
                 int32_t max_det, int32_t agnostic, float* dev_dets, int32_t* dev_counts, void* stream);
-/* U7 process_mask(upsample=True) + threshold. */
+/* U7 process_mask(upsample=True) + threshold.  Writes slots [0, min(offsets[B], capacity)) of dev_masks completely; slots
+ * beyond that are left untouched (no whole-buffer memset: the cost follows the number of instances, not the capacity). */
 int32_t vti_masks(vti_ctx* ctx, const float* dev_dets, const int32_t* dev_counts, const void* dev_proto,
                   int32_t B, int32_t max_det, int32_t mode, int32_t packing,
                   uint8_t* dev_masks, int32_t capacity, int32_t* dev_offsets, void* stream);

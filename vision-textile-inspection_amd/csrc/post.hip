@@ -480,7 +480,7 @@ constexpr int MT = 64;          // output tile edge
 constexpr int ML = MT / 4 + 3;  // low-res rows/cols needed by one tile at the fixed 1/4 scale (+ slack)
 
 // Plan: exclusive prefix sums of the counts, then one work item per (instance slot, 64x64 output tile)
-// whose low-res footprint can intersect the instance's crop box.  Everything else stays zero (memset).
+// whose low-res footprint can intersect the instance's crop box.  The live slots are zeroed first (mask_clear_kernel).
 // item = slot * tiles + tile.  One workgroup; B and the detection counts are small.
 __global__ __launch_bounds__(256) void mask_offsets_kernel(const int* __restrict__ counts, int B, int max_det,
                                                            int* __restrict__ offsets, int* __restrict__ nitems) {
@@ -497,6 +497,35 @@ __global__ __launch_bounds__(256) void mask_offsets_kernel(const int* __restrict
     for (int b = threadIdx.x; b <= B; b += 256) offsets[b] = s_off[b];
 }
 
+// frame and instance of output slot `slot` (largest b with offsets[b] <= slot)
+__device__ __forceinline__ void mask_slot_owner(const int* __restrict__ offsets, int B, int slot, int& b, int& inst) {
+    int lo = 0, hi = B;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (offsets[mid] <= slot) lo = mid; else hi = mid; }
+    b = lo; inst = slot - offsets[lo];
+}
+// tiles [tx0, tx1] x [ty0, ty1] that get a work item: a tile can be non-zero only if one of its bilinear taps lies inside the box
+// (in 1/4-res pixels); the box is expanded by 2 low-res pixels (= 8 output px) to be safe on every side.
+__device__ __forceinline__ bool mask_tile_rect(const float* __restrict__ d, int H, int W, int& tx0, int& tx1, int& ty0, int& ty1) {
+    const int tiles_x = (W + MT - 1) / MT, tiles_y = (H + MT - 1) / MT;
+    const float x1 = d[0] - 8.f, y1 = d[1] - 8.f, x2 = d[2] + 8.f, y2 = d[3] + 8.f;
+    tx0 = (int)floorf(x1 / MT); tx1 = (int)floorf(x2 / MT); ty0 = (int)floorf(y1 / MT); ty1 = (int)floorf(y2 / MT);
+    tx0 = max(tx0, 0); ty0 = max(ty0, 0); tx1 = min(tx1, tiles_x - 1); ty1 = min(ty1, tiles_y - 1);
+    return tx1 >= tx0 && ty1 >= ty0;
+}
+
+// Zeroes the live slots (everything a work item does not cover must read 0).  Slots at and beyond offsets[B] are not touched: a
+// 4096-slot buffer holding three instances costs three slots of writes, not a memset of the whole buffer.  Whole slots, full
+// lines: zeroing only the bytes outside each slot's tile rectangle was tried and is slower (partial-line writes: 109 MB took
+// 50 us where this takes ~23 us for 181 MB).  One workgroup per slot.
+__global__ __launch_bounds__(256) void mask_clear_kernel(const int* __restrict__ offsets, int B, int slot_bytes, int capacity,
+                                                         uint8_t* __restrict__ masks) {
+    const int slot = blockIdx.x;
+    if (slot >= min(offsets[B], capacity)) return;
+    uint4* b4 = (uint4*)(masks + (size_t)slot * slot_bytes);       // slot_bytes % 16 == 0 (checked by the launcher)
+    const int nvec = slot_bytes >> 4;
+    for (int v = threadIdx.x; v < nvec; v += 256) b4[v] = make_uint4(0u, 0u, 0u, 0u);
+}
+
 __global__ __launch_bounds__(256) void mask_plan_kernel(const float* __restrict__ dets, const int* __restrict__ offsets, int B,
                                                         int max_det, int row, int H, int W, int capacity,
                                                         int2* __restrict__ items, int* __restrict__ nitems,
@@ -504,10 +533,8 @@ __global__ __launch_bounds__(256) void mask_plan_kernel(const float* __restrict_
     const int slot = blockIdx.x * 256 + threadIdx.x;
     const int total = min(offsets[B], capacity);
     if (slot >= total) return;
-    const int tiles_x = (W + MT - 1) / MT, tiles_y = (H + MT - 1) / MT;
-    int lo = 0, hi = B;                         // largest b with offsets[b] <= slot
-    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (offsets[mid] <= slot) lo = mid; else hi = mid; }
-    const int inst = slot - offsets[lo];
+    int lo, inst;
+    mask_slot_owner(offsets, B, slot, lo, inst);
     const float* d = dets + ((size_t)lo * max_det + inst) * row;
     // fp16 prototypes, 32 coefficients: each fp32 coefficient c is split as c = h + l with h = half(c), l = half(c - h)
     // (exact to 2^-22 |c|), packed in channel pairs, so the tile kernel's dots run as v_dot2_f32_f16 (products exact, fp32
@@ -526,13 +553,9 @@ __global__ __launch_bounds__(256) void mask_plan_kernel(const float* __restrict_
     } else {
         big = 1u;
     }
-    // a tile can be non-zero only if one of its bilinear taps lies inside the box (in 1/4-res
-    // pixels); expand the box by 2 low-res pixels (= 8 output px) to be safe on every side
-    const float x1 = d[0] - 8.f, y1 = d[1] - 8.f, x2 = d[2] + 8.f, y2 = d[3] + 8.f;
-    int tx0 = (int)floorf(x1 / MT), tx1 = (int)floorf(x2 / MT), ty0 = (int)floorf(y1 / MT), ty1 = (int)floorf(y2 / MT);
-    tx0 = max(tx0, 0); ty0 = max(ty0, 0); tx1 = min(tx1, tiles_x - 1); ty1 = min(ty1, tiles_y - 1);
-    const int cnt = (tx1 >= tx0 && ty1 >= ty0) ? (tx1 - tx0 + 1) * (ty1 - ty0 + 1) : 0;
-    if (cnt == 0) return;
+    int tx0, tx1, ty0, ty1;
+    if (!mask_tile_rect(d, H, W, tx0, tx1, ty0, ty1)) return;
+    const int cnt = (tx1 - tx0 + 1) * (ty1 - ty0 + 1);
     int base = atomicAdd(nitems, cnt);
     for (int ty = ty0; ty <= ty1; ++ty)
         for (int tx = tx0; tx <= tx1; ++tx) items[base++] = make_int2((slot << 12) | (ty << 6) | tx, (int)((big << 31) | ((unsigned)lo << 16) | (unsigned)inst));   // tiles < 64 per side
@@ -780,9 +803,9 @@ hipError_t launch_masks(int dtype, const float* dets, const int* counts, const v
     if (capacity <= 0) return hipGetLastError();
     hipLaunchKernelGGL(mask_plan_kernel, dim3((capacity + 255) / 256), dim3(256), 0, st, dets, offsets, B, max_det, 6 + nm, H, W,
                        capacity, items, nitems, csplit);
-    const size_t out_bytes = (size_t)capacity * H * (packing == VTI_PACK_U8 ? W : W / 8);
-    hipError_t e = hipMemsetAsync(masks, 0, out_bytes, st);
-    if (e != hipSuccess) return e;
+    const size_t slot_bytes = (size_t)H * (packing == VTI_PACK_U8 ? W : W / 8);      // H, W multiples of 32: a multiple of 128
+    if ((slot_bytes & 15) || ((uintptr_t)masks & 15)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(mask_clear_kernel, dim3(capacity), dim3(256), 0, st, offsets, B, (int)slot_bytes, capacity, masks);
     // persistent blocks walk the work list: exactly as many as are resident at once (a second round of late blocks would run
     // on a mostly empty chip), a multiple of 8 for the per-XCD partition
     static int per_cu[4] = {0, 0, 0, 0};
