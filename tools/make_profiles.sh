@@ -16,7 +16,7 @@ tag = sys.argv[1]
 out = "gpurun_out/profiles"
 def fam(n):
     if "conv_kernel" in n or "stem_kernel" in n or "conv3_pk" in n or "conv1_pk" in n or "stem_l1" in n: return "conv family (conv3_pk + conv1_pk + conv_kernel + stem_l1_kernel)"
-    for k in ("decode_kernel", "masks_kernel", "nms_kernel", "nms_scan_kernel", "mask_plan_kernel", "mask_offsets_kernel",
+    for k in ("decode_kernel", "masks_kernel", "nms_kernel", "nms_scan_kernel", "mask_plan_kernel", "mask_clear_kernel", "mask_offsets_kernel",
               "sppf_pool", "upsample2x", "scale_boxes", "letterbox"):
         if k in n: return k
     return None
