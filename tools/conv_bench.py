@@ -21,6 +21,13 @@ SHAPES = {  # name: (c1, c2, k, s, kind, H_in, W_in)
     "c2f8_m_128-128_20": (128, 128, 3, 1, 0, 20, 20),
     "l7_128-256_s2": (128, 256, 3, 2, 0, 40, 40),
     "sppf_cv2_512-256": (512, 256, 1, 1, 0, 20, 20),
+    "sppf_cv1_256-128_20": (256, 128, 1, 1, 0, 20, 20),
+    "sppf_cv2_512-256_20": (512, 256, 1, 1, 0, 20, 20),
+    "c2f8_cv1_256-256_20": (256, 256, 1, 1, 0, 20, 20),
+    "c2f8_cv2_384-256_20": (384, 256, 1, 1, 0, 20, 20),
+    "l5_64-128_s2": (64, 128, 3, 2, 0, 80, 80),
+    "l16_64-64_s2": (64, 64, 3, 2, 0, 80, 80),
+    "l19_128-128_s2": (128, 128, 3, 2, 0, 40, 40),
     "stem": (3, 16, 3, 2, 0, 640, 640),
 }
 def main():
