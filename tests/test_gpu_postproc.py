@@ -150,6 +150,33 @@ def test_masks_hand_case_and_capacity():
     assert m.shape[0] == 0 and off.cpu().tolist() == [0, 0]
 
 
+@pytest.mark.parametrize("dtype", ["fp16", "fp32"])
+@pytest.mark.parametrize("packing", ["bits", "u8"])
+def test_masks_dirty_oversized_buffer(dtype, packing):
+    """vti_masks into a caller buffer that is larger than the instance count and full of garbage (include/vti.h): the live
+    slots come out exactly as into a fresh exact-size buffer (every byte no tile item covers is zeroed), the slots beyond the
+    instance count are not touched.  Ragged 736x960 geometry: a partial last tile column and row."""
+    need_gpu()
+    eng = _engine(nc=2, H=736, W=960, B=2, dtype=dtype)
+    rng = np.random.default_rng(17)
+    B, A = 2, eng.num_anchors
+    pred = synth_pred(rng, B, 2, 32, A, H=736, W=960, n_inst=12)
+    tdt = torch.float16 if dtype == "fp16" else torch.float32
+    proto_d = torch.from_numpy(rng.standard_normal((B, 184, 240, 32)).astype(np.float32)).to(tdt).cuda()
+    dets, counts = eng.nms(torch.from_numpy(pred).cuda(), 0.25, 0.7, 300)
+    ref, off = eng.masks(dets, counts, proto_d, "logit", packing)
+    total = int(off[-1])
+    assert total >= 4
+    wb = 960 if packing == "u8" else 960 // 8
+    buf = torch.full((total + 5, 736, wb), 0xAB, dtype=torch.uint8, device="cuda")
+    got, off2 = eng.masks(dets, counts, proto_d, "logit", packing, capacity=total + 5, masks=buf)
+    torch.cuda.synchronize()
+    assert torch.equal(off, off2) and got.data_ptr() == buf.data_ptr()
+    assert torch.equal(got[:total], ref)
+    assert bool((got[total:] == 0xAB).all())
+    assert int(ref.sum()) > 0
+
+
 @pytest.mark.parametrize("H0,W0,imgsz", [(960, 1280, 960), (480, 640, 640), (333, 517, 640), (1080, 1920, 640), (640, 640, 640)])
 def test_letterbox_bit_exact(H0, W0, imgsz):
     need_gpu()
