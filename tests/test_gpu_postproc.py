@@ -151,6 +151,37 @@ def test_masks_hand_case_and_capacity():
 
 
 @pytest.mark.parametrize("dtype", ["fp16", "fp32"])
+def test_masks_other_coefficient_count(dtype):
+    """nm = 16 (a model trained with fewer prototypes): the generic-nm instantiation of the tile kernel, and the fp16 engine
+    WITHOUT the split-coefficient table (it exists for nm = 32 only)."""
+    need_gpu()
+    import vti_amd
+    eng = vti_amd.Engine("n", 3, H=320, W=320, max_batch=2, dtype=dtype, nm=16)
+    eng.load_weights(vti_amd.random_weights(eng, seed=2), 0)
+    rng = np.random.default_rng(5)
+    B = 2
+    pred = synth_pred(rng, B, 3, 16, eng.num_anchors, H=320, W=320, n_inst=9)
+    proto = rng.standard_normal((B, 80, 80, 16)).astype(np.float32)
+    tdt = torch.float16 if dtype == "fp16" else torch.float32
+    proto_d = torch.from_numpy(proto).to(tdt).cuda()
+    dets, counts = eng.nms(torch.from_numpy(pred).cuda(), 0.25, 0.7, 300)
+    masks, offsets = eng.masks(dets, counts, proto_d, "logit", "u8")
+    bits, _ = eng.masks(dets, counts, proto_d, "logit", "bits")
+    torch.cuda.synchronize()
+    assert torch.equal(vti_amd.unpack_bits(bits, 320), masks)
+    off = offsets.cpu().numpy()
+    worst = 1.0
+    for b in range(B):
+        d = dets[b, :counts[b]].cpu().numpy()
+        ref = process_mask(proto_d[b].float().cpu().permute(2, 0, 1), d[:, 6:], d[:, :4], (320, 320), "logit").numpy()
+        got = masks[off[b]:off[b + 1]].cpu().numpy()
+        assert len(d) == 9 and ref.sum() > 0
+        for i in range(len(d)):
+            worst = min(worst, mask_iou(got[i], ref[i]))
+    assert worst >= 0.999, worst
+
+
+@pytest.mark.parametrize("dtype", ["fp16", "fp32"])
 @pytest.mark.parametrize("packing", ["bits", "u8"])
 def test_masks_dirty_oversized_buffer(dtype, packing):
     """vti_masks into a caller buffer that is larger than the instance count and full of garbage (include/vti.h): the live
