@@ -542,8 +542,12 @@ __global__ __launch_bounds__(256) void mask_plan_kernel(const float* __restrict_
     unsigned big = 0;
     if (csplit && row == 6 + 32) {
         unsigned* cs = csplit + (size_t)slot * 32;
+        float2 cf[16];                     // all 16 loads first: consumed inside the loop they would be waited for one by one
+#pragma unroll
+        for (int k = 0; k < 16; ++k) cf[k] = *(const float2*)(d + 6 + 2 * k);       // rows are 152 bytes: 8-byte aligned
+#pragma unroll
         for (int k = 0; k < 16; ++k) {
-            const float c0 = d[6 + 2 * k], c1 = d[6 + 2 * k + 1];
+            const float c0 = cf[k].x, c1 = cf[k].y;
             if (!(fabsf(c0) < 3.0e4f) || !(fabsf(c1) < 3.0e4f)) big = 1u;
             const half_t h0 = (half_t)c0, h1 = (half_t)c1;
             const half_t l0 = (half_t)(c0 - (float)h0), l1 = (half_t)(c1 - (float)h1);
@@ -801,11 +805,12 @@ hipError_t launch_masks(int dtype, const float* dets, const int* counts, const v
     if (max_det > 65535 || B > 32767 || H > 64 * MT || W > 64 * MT || capacity > (1 << 19)) return hipErrorInvalidValue;    // item record fields
     hipLaunchKernelGGL(mask_offsets_kernel, dim3(1), dim3(256), (size_t)(B + 1) * sizeof(int), st, counts, B, max_det, offsets, nitems);
     if (capacity <= 0) return hipGetLastError();
-    hipLaunchKernelGGL(mask_plan_kernel, dim3((capacity + 255) / 256), dim3(256), 0, st, dets, offsets, B, max_det, 6 + nm, H, W,
-                       capacity, items, nitems, csplit);
     const size_t slot_bytes = (size_t)H * (packing == VTI_PACK_U8 ? W : W / 8);      // H, W multiples of 32: a multiple of 128
     if ((slot_bytes & 15) || ((uintptr_t)masks & 15)) return hipErrorInvalidValue;
+    // (running the clear on a side stream next to the plan was tried: the two event hops cost more than the 13 us they hide)
     hipLaunchKernelGGL(mask_clear_kernel, dim3(capacity), dim3(256), 0, st, offsets, B, (int)slot_bytes, capacity, masks);
+    hipLaunchKernelGGL(mask_plan_kernel, dim3((capacity + 255) / 256), dim3(256), 0, st, dets, offsets, B, max_det, 6 + nm, H, W,
+                       capacity, items, nitems, csplit);
     // persistent blocks walk the work list: exactly as many as are resident at once (a second round of late blocks would run
     // on a mostly empty chip), a multiple of 8 for the per-XCD partition
     static int per_cu[4] = {0, 0, 0, 0};
