@@ -13,7 +13,14 @@ then shares the chip, which is why `roofline.isolated` also reports the same for
 and every step scatters the next batch / gathers the previous batch's detections + bit-packed masks
 over RCCL (xGMI) on a side stream, overlapped with compute (weak scaling: 64 frames per GPU).
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+Before the W warm-up steps the chip is pre-heated with >= --preheat seconds of the same steps (clocks sag under sustained
+MFMA load; a 20-step run is only ~50 ms long), so the timed steps land on settled clocks.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with these extra objects:
+  parity       -- the benchmarked engine (fp16) against the fp32 CPU oracle on a few of the bench frames, AFTER the timed
+                  region: mask IoU, |d box| in px and normalised, kept-set equality (north_star: IoU >= 0.999, |d box| < 1e-3).
+  fp32_engine  -- the same pipeline on the exact-f32 MFMA engine (the dtype that meets the north-star tolerance): its own
+                  frames/s, roofline fraction against the f32 matrix peak, and its parity object.
   roofline     -- the conv network (76 MFMA conv launches, >85 % of the step) against the dense fp16
                   MFMA peak: achieved = 2*MAC of all convs per forward / forward time measured with HIP
                   events on the launch stream inside the timed region.
@@ -35,6 +42,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 MFMA_PEAK_TFLOPS = 2517.0      # dense fp16: 256 CU x 4 SIMD x 1024 FLOP/clk x 2.4 GHz (MI355X_MICROARCH.md: ~2.5 PF)
+F32_MFMA_PEAK_TFLOPS = 157.3   # f32-input MFMA (v_mfma_f32_16x16x4_f32): 64 FLOP/clk/SIMD = 1/16 of the fp16 rate (same guide)
 HBM_PEAK_GBS = 8000.0
 CONF, IOU, MAX_DET = 0.25, 0.7, 300      # Ultralytics predict() defaults
 SLOTS_PER_FRAME = 64                     # mask output capacity = B * SLOTS_PER_FRAME instances (shared by the batch)
@@ -55,8 +63,9 @@ def calibrated_weights(vti_amd, eng, frames, conf, target):
     return blob, bias
 
 
-def cpu_baseline(blob, H, W, nc, budget_s=20.0):
-    """The oracle's full pipeline (fp32) on the host cores: bs=8 batches until ~budget_s of CPU work."""
+def cpu_baseline(blob, H, W, nc, budget_s=12.0):
+    """The oracle's full pipeline (fp32) on the host cores.  `value` is the bs=8 rate (about budget_s of CPU work);
+    `by_batch` adds bs=1 and bs=64, `stage_ms_per_frame` the split at bs=8."""
     from oracle.model import OracleModel
     from oracle.postproc import non_max_suppression, process_mask, scale_boxes
     # host threads: the cores this process may actually use (a 1-GPU box grants 16 of the host's
@@ -69,28 +78,93 @@ def cpu_baseline(blob, H, W, nc, budget_s=20.0):
     torch.set_num_threads(threads)
     om = OracleModel(blob, H, W, "fp32")
     rng = np.random.Generator(np.random.PCG64(0))
-    bs = 8
-    frames = rng.integers(0, 256, (bs, H, W, 3), dtype=np.uint8)
+    stage = {"net": 0.0, "nms": 0.0, "masks": 0.0}
 
-    def one():
+    def one(frames):
+        t0 = time.perf_counter()
         pred, proto = om.forward_u8(frames, swap_rb=True)
+        t1 = time.perf_counter()
         dets = non_max_suppression(pred.numpy(), CONF, IOU, MAX_DET, nc=nc)
+        t2 = time.perf_counter()
         for b, d in enumerate(dets):
             if len(d):
                 process_mask(proto[b], d[:, 6:], d[:, :4], (H, W), "logit")
                 scale_boxes((H, W), d[:, :4], (H, W))
-    one()                                   # warm-up (oneDNN primitive creation)
+        t3 = time.perf_counter()
+        stage["net"] += t1 - t0; stage["nms"] += t2 - t1; stage["masks"] += t3 - t2
+
+    def rate(bs, budget, max_it):
+        frames = rng.integers(0, 256, (bs, H, W, 3), dtype=np.uint8)
+        one(frames)                             # warm-up (oneDNN primitive creation for this batch size)
+        for k in stage: stage[k] = 0.0
+        t0 = time.perf_counter()
+        it = 0
+        while True:
+            one(frames)
+            it += 1
+            dt = time.perf_counter() - t0
+            if dt > budget or it >= max_it:
+                break
+        return bs * it / dt, it, dt
+
+    v8, it8, dt8 = rate(8, budget_s, 32)
+    split = {k: round(v / (8 * it8) * 1e3, 3) for k, v in stage.items()}
+    v1, it1, dt1 = rate(1, 3.0, 16)
+    v64, it64, dt64 = rate(64, 4.0, 2)
+    return dict(value=round(v8, 3), unit="frames/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{it8} iterations of bs=8 {H}x{W} frames, full predict pipeline "
+                       f"(net fp32 + NMS + process_mask), torch-CPU oracle, {dt8:.1f} s",
+                by_batch={"1": round(v1, 3), "8": round(v8, 3), "64": round(v64, 3)},
+                by_batch_sample=f"bs=1: {it1} it / {dt1:.1f} s; bs=64: {it64} it / {dt64:.1f} s",
+                stage_ms_per_frame=split)
+
+
+def parity_check(eng, blob, frames_dev, nc, H, W, n_frames):
+    """The engine's detections + masks for the first n_frames bench frames against the fp32 CPU oracle (checker only;
+    runs after the timed region)."""
+    from oracle import parity as op
+    fr = frames_dev[:n_frames].contiguous()
+    got = op.engine_predict(eng, fr, CONF, IOU, MAX_DET)
+    want = op.oracle_predict(blob, fr.cpu().numpy(), nc, CONF, IOU, MAX_DET, mode="fp32")
+    res = op.compare(got, want, H, W)
+    res["frames"] = n_frames
+    res["oracle"] = "torch-CPU fp32 restatement of Ultralytics predict (oracle/, parity unpinned)"
+    return res
+
+
+def fp32_engine_line(vti_amd, blob, frames, B, H, W, nc, cap, dev, n_par, steps=5, warmup=2):
+    """The same pipeline on the exact-f32 MFMA engine (the dtype whose results meet the north-star tolerance): frames/s,
+    its own roofline fraction (against the f32 matrix peak) and its parity against the fp32 CPU oracle."""
+    eng = vti_amd.Engine("n", nc, H=H, W=W, max_batch=B, dtype="fp32")
+    eng.load_weights(blob, torch.cuda.current_device())
+    o = eng.alloc_outputs(B, MAX_DET, cap, "bits", dev)
+    st = torch.cuda.current_stream()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * steps)]
+
+    def step(i=None):
+        if i is not None: ev[2 * i].record(st)
+        eng.forward(frames, True, pred=o["pred"], proto=o["proto"])
+        if i is not None: ev[2 * i + 1].record(st)
+        eng.nms(o["pred"], CONF, IOU, MAX_DET, False, dets=o["dets"], counts=o["counts"])
+        eng.masks(o["dets"], o["counts"], o["proto"], "logit", "bits", capacity=cap, masks=o["masks"], offsets=o["offsets"])
+        eng.scale_boxes(o["dets"], o["counts"], H, W, xyxy=o["xyxy"])
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
-    it = 0
-    while True:
-        one()
-        it += 1
-        dt = time.perf_counter() - t0
-        if dt > budget_s or it >= 32:
-            break
-    return dict(value=round(bs * it / dt, 3), unit="frames/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"{it} iterations of bs={bs} {H}x{W} frames, full predict pipeline "
-                       f"(net fp32 + NMS + process_mask), torch-CPU oracle, {dt:.1f} s")
+    for i in range(steps):
+        step(i)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    fwd_ms = float(np.mean([ev[2 * i].elapsed_time(ev[2 * i + 1]) for i in range(steps)]))
+    ach = 2.0 * eng.macs_per_frame * B / (fwd_ms * 1e-3) / 1e12
+    res = dict(dtype="f32", value=round(B * steps / dt, 1), unit="frames/s", steps=steps, warmup=warmup, ms_per_step=round(dt / steps * 1e3, 4),
+               roofline=dict(bound="mfma", achieved=round(ach, 2), peak=F32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                             frac=round(ach / F32_MFMA_PEAK_TFLOPS, 5), avg_ms=round(fwd_ms, 4)),
+               note="same weights, frames and pipeline as the headline line, exact-f32 MFMA (v_mfma_f32_16x16x4_f32), fp32 activations")
+    if n_par > 0:
+        res["parity"] = parity_check(eng, blob, frames, nc, H, W, n_par)
+    return res
 
 
 def main():
@@ -102,6 +176,12 @@ def main():
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exchange", action="store_true", help="N>1: skip the per-step scatter/gather")
+    ap.add_argument("--gather-masks", action="store_true",
+                    help="N>1: also ship every rank's LIVE bit-packed mask slots to the root each step (variable-length point-to-point "
+                         "gather, one host read of the slot count per step); default: dets/counts/xyxy + on-device reductions only")
+    ap.add_argument("--preheat", type=float, default=1.0, help="seconds of untimed steps before the warm-up steps (clock settling)")
+    ap.add_argument("--parity-frames", type=int, default=2, help="bench frames checked against the fp32 CPU oracle after the timed region (0: skip)")
+    ap.add_argument("--no-fp32-line", action="store_true", help="skip the secondary fp32-engine measurement + parity")
     ap.add_argument("--pipeline", action="store_true",
                     help="overlap post-processing of batch k-1 with the network of batch k on a second stream: ~6 %% more frames/s "
                          "(24.7k vs 23.2k on one MI355X), but the forward then shares the chip and its in-region HIP-event time (the "
@@ -137,9 +217,14 @@ def main():
     cap = B * SLOTS_PER_FRAME
     outs = [eng.alloc_outputs(B, MAX_DET, cap, "bits", dev) for _ in range(2)]
     shards = [frames, frames.clone()]
+    FABRIC_CLS = 1                          # the reference's FABRIC_CLASS_ID (config.py:70): whose union envelope the consumer reads
 
     exchange = world > 1 and not args.no_exchange
-    exch_note = "none (single GPU)" if world == 1 else "disabled"
+    exch_note = "none (single GPU)" if world == 1 else "disabled (--no-exchange)"
+    if exchange:                            # what the consumer needs from a frame travels, not the mask buffer
+        for o in outs:
+            o["stats"] = torch.empty((cap, 5), dtype=torch.int64, device=dev)
+            o["envelope"] = torch.empty((B, W), dtype=torch.int32, device=dev)
     comm = torch.cuda.Stream(device=dev) if exchange else None
     root_pool = None
     if exchange and rank == 0:       # the node's frames live on the root GPU
@@ -169,6 +254,8 @@ def main():
                     comm.wait_stream(main_stream)
                 shards[nxt] = dp.scatter_frames(root_pool, B, (H, W, 3), dev)
                 dp.gather_detections(outs[nxt])
+                if args.gather_masks:
+                    dp.gather_live_masks(outs[nxt]["masks"], outs[nxt]["offsets"])
                 ready = torch.cuda.Event()
                 ready.record(comm)
         x, o = shards[cur], outs[cur]
@@ -187,6 +274,9 @@ def main():
             eng.nms(o["pred"], CONF, IOU, MAX_DET, False, dets=o["dets"], counts=o["counts"])
             eng.masks(o["dets"], o["counts"], o["proto"], "logit", "bits", capacity=cap, masks=o["masks"], offsets=o["offsets"])
             eng.scale_boxes(o["dets"], o["counts"], H, W, xyxy=o["xyxy"])
+            if exchange:                    # consumer reductions straight from the bit-packed masks: the gather's payload
+                eng.mask_stats_bits(o["masks"], H, W, stats=o["stats"], offsets=o["offsets"])
+                eng.envelope_bits(o["masks"], o["offsets"], o["dets"], FABRIC_CLS, H, W, envelope=o["envelope"])
             if timed_idx is not None:
                 ev_end[timed_idx].record(post_stream)
             post_done[cur] = torch.cuda.Event()
@@ -201,14 +291,31 @@ def main():
         torch.cuda.synchronize()
 
     if exchange:
+        # a failing exchange is fatal (exit code != 0): a scaling number without it is not a sharded run; --no-exchange says so explicitly
         try:
             step(0)
             torch.cuda.synchronize()
-            exch_note = "per step: RCCL scatter of uint8 frames from rank 0 + gather of dets/counts/xyxy/bit-packed masks, side stream, overlapped"
-        except Exception as e:                       # keep the scaling run alive, say so in the JSON
-            exchange, comm = False, None
-            shards[1] = frames.clone()
-            exch_note = f"failed, ran without: {type(e).__name__}: {e}"[:200]
+        except Exception as e:
+            print(f"bench.py: rank {rank}: the RCCL scatter/gather step failed ({type(e).__name__}: {e}); "
+                  f"fix it or pass --no-exchange", file=sys.stderr, flush=True)
+            sys.exit(3)
+        exch_note = ("per step: RCCL scatter of uint8 frames from rank 0 + gather of dets/counts/xyxy/offsets + on-device consumer "
+                     "reductions (per-instance moments/extents, per-frame fabric envelope), side stream, overlapped"
+                     + ("; + live bit-packed mask slots (variable length)" if args.gather_masks else ""))
+    # pre-heat: sustained load until the clocks have settled (untimed), then the W warm-up steps of the contract
+    t_heat = time.perf_counter()
+    n_heat = 0
+    while True:
+        for _ in range(8):
+            step(n_heat); n_heat += 1
+        torch.cuda.synchronize()
+        heated = time.perf_counter() - t_heat
+        if world > 1:                                # every rank must run the same number of (collective) steps
+            heated = dp.max_over_ranks(heated, dev)
+        if heated >= args.preheat:
+            break
+    if n_heat & 1:                                   # keep the double-buffer phase: step k uses buffer k & 1
+        step(n_heat); n_heat += 1
     for k in range(args.warmup):
         step(k)
     barrier()
@@ -239,12 +346,13 @@ def main():
     value = total_frames / elapsed
     flops_per_forward = 2.0 * eng.macs_per_frame * B
     achieved = flops_per_forward / (fwd_ms * 1e-3) / 1e12
+    peak = MFMA_PEAK_TFLOPS if args.dtype == "fp16" else F32_MFMA_PEAK_TFLOPS
 
     # HBM bytes per forward from the committed rocprofv3 PMC passes (tools/make_profiles.sh): only
     # valid for the configuration they were collected on.
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-    if os.path.exists(tpath) and B == 64 and args.dtype == "fp16":
+    tpath = next((q for q in (os.path.join(ROOT, "profiles", f"r{r:02d}_hbm_traffic.json") for r in range(9, 0, -1)) if os.path.exists(q)), "")
+    if tpath and B == 64 and args.dtype == "fp16":
         fam = json.load(open(tpath))["families"]
         traffic = sum(v["total_bytes"] for k, v in fam.items() if k.startswith("conv family") or k in ("decode_kernel", "sppf_pool", "upsample2x"))    # the forward's kernels
 
@@ -261,16 +369,24 @@ def main():
                        "pipeline": ("post-processing of batch k overlaps the network of batch k+1 on a second stream"
                                     if pipelined else "network and post-processing in series"),
                        "mask_capacity": cap, "masks_dropped": max(0, int(outs[(args.steps - 1) & 1]["offsets"][-1].item()) - cap), "parallelism": f"dp{world}", "exchange": exch_note},
-            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / MFMA_PEAK_TFLOPS, 5), "traffic": traffic,
-                         "traffic_note": "HBM bytes per forward (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes, profiles/r01_hbm_traffic.json); algorithmic unfused activation bytes = 91.6 MB/frame",
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(achieved / peak, 5), "traffic": traffic,
+                         "traffic_note": "HBM bytes per forward (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes, profiles/" + os.path.basename(tpath) + "); algorithmic unfused activation bytes = 91.6 MB/frame",
                          "kernel": f"vti conv family: conv3_pk / conv1_pk (persistent LDS-DMA 3x3 / 1x1) + conv_kernel (fused towers, stride 2) + stem_l1_kernel ({eng.num_launches} launches per forward incl. the SPPF pool; {len(eng.conv_table())} convs, {sum(1 for t in eng.conv_table() if t['fused'])} fused into their producer's kernel, decode fused into the box towers)",
                          "flop_per_launch": flops_per_forward, "avg_ms": round(fwd_ms, 4),
                          "isolated": {"avg_ms": round(iso_ms, 4), "achieved": round(flops_per_forward / (iso_ms * 1e-3) / 1e12, 2),
-                                      "frac": round(flops_per_forward / (iso_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 5),
+                                      "frac": round(flops_per_forward / (iso_ms * 1e-3) / 1e12 / peak, 5),
                                       "note": f"the same forward alone on the chip, {n_iso} back-to-back launches after the timed region"}},
             "stage_ms": {"forward": round(fwd_ms, 4), "nms+masks+scale_boxes": round(post_ms, 4)},
         }
+        line["config"]["preheat"] = f"{n_heat} untimed steps over >= {args.preheat:.1f} s before the {args.warmup} warm-up steps"
+        if args.parity_frames > 0:
+            line["parity"] = parity_check(eng, blob, frames, nc, H, W, min(args.parity_frames, B))
+            line["parity"]["engine"] = line["dtype"]
+            line["parity"]["tolerance"] = ("north_star gate: mask IoU >= 0.999 and |d box| < 1e-3 (normalised by 640) with the same kept set; "
+                                           "see meets_north_star -- the fp16 engine is reported as measured, the fp32 engine line beside it meets the gate")
+        if world == 1 and args.dtype == "fp16" and not args.no_fp32_line:
+            line["fp32_engine"] = fp32_engine_line(vti_amd, blob, frames, B, H, W, nc, cap, dev, min(args.parity_frames, B))
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(blob, H, W, nc)
         print(json.dumps(line), flush=True)

@@ -21,7 +21,12 @@
  *    allocation is the packed weight image made by vti_load_weights.
  *  - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream).
  *    Calls enqueue work on it and return; no hidden synchronisation.
- *  - One ctx per (device, host thread) (main.py:187-211: single-threaded use).
+ *  - One ctx per (device, host thread) (main.py:187-211: single-threaded use).  A ctx is bound to the device passed to
+ *    vti_load_weights; entry points that launch work return VTI_ERR_STATE when another device is current.
+ *  - Multi-GPU is one process per GPU above this ABI: frames are independent, so the only exchange steps
+ *    are a scatter of uint8 frames and a gather of detections + consumer reductions, done by the host shim with
+ *    torch.distributed (backend "nccl" = RCCL over xGMI; vti_amd/dataparallel.py).  The library itself opens no communicator
+ *    and exports no vti_dp_* entry points: there is no collective inside the model.
  *  - Tensor layouts (T = fp16 or fp32 per vti_desc.dtype):
  *      frames   u8  [B,H0,W0,3]           camera frames, any channel order (see swap_rb)
  *      input    u8  [B,H,W,3]             letterboxed frames (H,W multiples of 32)
@@ -64,6 +69,9 @@ enum { VTI_F16 = 0, VTI_F32 = 1 };
 enum { VTI_MASK_LOGIT = 0,     /* current Ultralytics: crop, bilinear upsample, > 0.0 */
        VTI_MASK_SIGMOID = 1 }; /* Ultralytics 8.0.x : sigmoid, crop, upsample, > 0.5  */
 enum { VTI_PACK_U8 = 0, VTI_PACK_BITS = 1 };
+/* vti_masks work-list size: one call handles at most max_batch * VTI_MASK_SLOTS_PER_FRAME instances (capacity above that is
+ * VTI_ERR_UNSUPPORTED); vti_workspace_bytes() is sized for it.  Ultralytics' default max_det is 300, the reference's 200. */
+#define VTI_MASK_SLOTS_PER_FRAME 512
 
 /* Model description: replaces what YOLO(model_path) reads out of the .pt (measurement.py:145). */
 typedef struct {
@@ -112,8 +120,8 @@ int32_t vti_load_weights(vti_ctx* ctx, const void* host_blob, size_t nbytes, int
 int32_t vti_set_workspace(vti_ctx* ctx, void* dev_ws, size_t nbytes);
 
 /* ---- the hot path: stages of predict() ------------------------------------------- */
-/* U1 LetterBox: resize (OpenCV u8 INTER_LINEAR fixed point) + pad 114 to HxW.  A frame
- * already HxW is copied through. */
+/* U1 LetterBox: resize (OpenCV u8 INTER_LINEAR fixed point; the rounded 2x2 box mean OpenCV substitutes -- INTER_AREA --
+ * when the frame is exactly twice the resized size) + pad 114 to HxW.  A frame already HxW is copied through. */
 int32_t vti_letterbox(vti_ctx* ctx, const uint8_t* dev_frames, int32_t B, int32_t H0, int32_t W0,
                       uint8_t* dev_input, void* stream);
 /* U2-U5 network forward.  swap_rb=1 reproduces Ultralytics' channel flip of ndarray sources. */
@@ -151,6 +159,35 @@ int32_t vti_union_envelope(vti_ctx* ctx, const uint8_t* dev_bitmaps, const int32
  * (min/max = -1 when empty). */
 int32_t vti_mask_stats(vti_ctx* ctx, const uint8_t* dev_bitmaps, int32_t n, int32_t H0, int32_t W0,
                        int64_t* dev_stats, void* stream);
+
+/* The same reductions straight from the BIT-PACKED masks vti_masks writes (VTI_PACK_BITS, u8 [n,H,W/8]); the nearest resize of
+ * A4 is folded into integer weights, so no [n,H0,W0] bitmap is materialised.  Results are identical to
+ * vti_mask_to_frame followed by vti_mask_stats / vti_union_envelope.
+ * A4+A7: i64 {m00, m10, m01, min_col, max_col} per instance (measurement.py:70-86,302-318).  dev_n_live (may be NULL) points
+ * at the number of live slots of a fixed-capacity buffer (&dev_offsets[B] of vti_masks): slots at and beyond it are not read
+ * and report the empty mask {0,0,0,-1,-1}. */
+int32_t vti_mask_stats_bits(vti_ctx* ctx, const uint8_t* dev_masks_bits, int32_t n, const int32_t* dev_n_live,
+                            int32_t H, int32_t W, int32_t H0, int32_t W0, int64_t* dev_stats, void* stream);
+/* A4+A5+A6, batched: envelope i32 [B,W0] = per frame and frame column the largest row covered by any of the frame's instances of
+ * class `cls` (cls < 0: every instance), -1 if none (measurement.py:70-86,160-185; the reference selects FABRIC_CLASS_ID,
+ * config.py:70).  dev_offsets / dev_dets / capacity as written by vti_masks / vti_nms; H, W are the ctx's. */
+int32_t vti_envelope_bits(vti_ctx* ctx, const uint8_t* dev_masks_bits, const int32_t* dev_offsets, const float* dev_dets,
+                          int32_t B, int32_t max_det, int32_t capacity, int32_t cls, int32_t H0, int32_t W0,
+                          int32_t* dev_envelope, void* stream);
+
+/* ---- measurement geometry, float64 as the reference; ctx may be NULL ------------------------ */
+/* pixel_to_world_using_camera_plane (measurement.py:50-65) for n points: cv2.undistortPoints (5 fixed-point iterations of the
+ * k1,k2,p1,p2,k3 model) + ray / fabric-plane intersection with the plane of compute_camera_plane (measurement.py:44-48).
+ * dev_uv f64 [n,2]; host_K f64[9] row-major, host_dist f64[5], host_R f64[9] row-major, host_t f64[3] in HOST memory
+ * (camera_calibration.json / extrinsics.json); dev_xyz f64 [n,3] world metres; dev_valid i32 [n] (0 where the reference
+ * returns None: |n . ray| < 1e-9). */
+int32_t vti_pixels_to_world(vti_ctx* ctx, const double* dev_uv, int32_t n, const double* host_K, const double* host_dist,
+                            const double* host_R, const double* host_t, double* dev_xyz, int32_t* dev_valid, void* stream);
+/* kmeans_1d_two_clusters (measurement.py:88-113), batched: dev_values f64 [B,max_n] (counts[b] valid entries per row, max_n <=
+ * 1024) -> dev_labels i32 [B,max_n] (0 beyond counts[b]), dev_centers f64 [B,2]; same iteration and exit rules, means summed in
+ * numpy's pairwise order. */
+int32_t vti_kmeans1d2(vti_ctx* ctx, const double* dev_values, const int32_t* dev_counts, int32_t B, int32_t max_n,
+                      int32_t max_iters, int32_t* dev_labels, double* dev_centers, void* stream);
 
 /* ---- per-layer access for parity tests ------------------------------------------- */
 /* Copies the activation written by conv `i` of the last vti_forward into dev_out as

@@ -57,10 +57,15 @@ def _linear_tables(ssize, dsize, horizontal):
 
 def resize_linear_u8(img, new_w, new_h):
     """cv2.resize(img, (new_w,new_h), interpolation=cv2.INTER_LINEAR) for uint8 HxWxC.
-    (OpenCV swaps in INTER_AREA when both scales are exactly 2 -- not restated; callers
-    in this repo never hit that case.)"""
+    OpenCV (imgproc/resize.cpp, hal::resize) swaps in INTER_AREA when both scales are exactly 2
+    (`interpolation == INTER_LINEAR && is_area_fast && iscale_x == 2 && iscale_y == 2`): the u8 fast path is the
+    rounded 2x2 box mean (a + b + c + d + 2) >> 2 (ResizeAreaFastVec_SIMD_8u: v_rshr_pack<2>).  A 1280x1280 frame at
+    imgsz=640 takes that path."""
     img = np.asarray(img, dtype=np.uint8)
     H0, W0 = img.shape[:2]
+    if W0 == 2 * new_w and H0 == 2 * new_h:
+        s = img.astype(np.int32)
+        return ((s[0::2, 0::2] + s[0::2, 1::2] + s[1::2, 0::2] + s[1::2, 1::2] + 2) >> 2).astype(np.uint8)
     xi, xa0, xa1 = _linear_tables(W0, new_w, True)
     yi, ya0, ya1 = _linear_tables(H0, new_h, False)
     src = img.astype(np.int32)

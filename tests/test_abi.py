@@ -103,6 +103,19 @@ def test_letterbox_shape_matches_oracle():
         g = letterbox_geometry(h0, w0, imgsz)
         assert letterbox_shape(h0, w0, imgsz) == (g["H"], g["W"])
     assert letterbox_shape(960, 1280, 960) == (736, 960)      # the reference's real input
+    assert letterbox_shape(960, 1280, 950) == (736, 960)      # Ultralytics check_imgsz: imgsz rounds UP to a multiple of the stride
+    assert letterbox_shape(600, 600, 610) == (640, 640)
+
+
+def test_letterbox_2x_downscale_is_the_box_mean():
+    """OpenCV swaps INTER_LINEAR for INTER_AREA at an exact 2x downscale: rounded mean of each 2x2 block."""
+    from oracle.letterbox import letterbox
+    img = np.zeros((4, 4, 3), np.uint8)
+    img[0, 0] = (1, 2, 3); img[0, 1] = (2, 2, 3); img[1, 0] = (1, 3, 255); img[1, 1] = (2, 2, 254)
+    img[2:, 2:] = 200
+    out, g = letterbox(img, 2, auto=False)
+    assert (g["new_h"], g["new_w"], g["top"], g["left"]) == (2, 2, 0, 0)
+    assert out[0, 0].tolist() == [2, 2, 129] and out[1, 1].tolist() == [200, 200, 200] and out[0, 1].tolist() == [0, 0, 0]
 
 
 def test_product_never_imports_the_oracle():

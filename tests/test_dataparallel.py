@@ -29,17 +29,32 @@ def _worker(rank, world, port, q):
         lo, hi = dp.shard_range(world * per, world, rank)
         expect = torch.arange(world * per * 8 * 8 * 3, dtype=torch.int64).remainder(251).to(torch.uint8).view(world * per, *tail)[lo:hi]
         ok = torch.equal(shard, expect)
-        # each rank "detects": counts = frame index, dets filled with rank
+        # each rank "detects": counts = frame index, dets filled with rank; rank r has 2 + r live mask slots of 5
+        live = 2 + rank
+        masks = torch.full((5, 8, 1), 200 + rank, dtype=torch.uint8)        # dead slots: must not travel
+        masks[:live] = rank
         out = dict(dets=torch.full((per, 4, 38), float(rank)), counts=torch.arange(lo, hi, dtype=torch.int32),
-                   xyxy=torch.full((per, 4, 4), float(rank)), masks=torch.full((5, 8, 1), rank, dtype=torch.uint8),
-                   offsets=torch.arange(per + 1, dtype=torch.int32))
+                   xyxy=torch.full((per, 4, 4), float(rank)), masks=masks,
+                   offsets=torch.tensor([0, 1, 2, live], dtype=torch.int32),
+                   stats=torch.full((5, 5), rank, dtype=torch.int64), envelope=torch.full((per, 16), rank - 1, dtype=torch.int32))
         got = dp.gather_detections(out)
         if rank == 0:
+            ok &= set(got) == {"dets", "counts", "xyxy", "offsets", "stats", "envelope"}       # compact payload: no mask buffer
             ok &= got["counts"].tolist() == list(range(world * per))
             ok &= got["dets"].shape == (world * per, 4, 38) and float(got["dets"][per:].min()) == 1.0
-            ok &= got["masks"].shape == (world * 5, 8, 1) and int(got["masks"][5:].max()) == 1
+            ok &= got["stats"].shape == (world * 5, 5) and int(got["stats"][5:].min()) == 1
+            ok &= got["envelope"].shape == (world * per, 16) and got["envelope"][per:].tolist() == [[0] * 16] * per
         else:
             ok &= got is None
+        few = dp.gather_detections(dict(dets=out["dets"], counts=out["counts"], xyxy=out["xyxy"], offsets=out["offsets"]))
+        ok &= (few is None) if rank else (set(few) == {"dets", "counts", "xyxy", "offsets"})
+        lm = dp.gather_live_masks(out["masks"], out["offsets"])
+        if rank == 0:
+            buf, n_live = lm
+            ok &= n_live.tolist() == [2, 3] and buf.shape == (5, 8, 1)
+            ok &= buf[:2].eq(0).all().item() and buf[2:].eq(1).all().item()
+        else:
+            ok &= lm is None
         ok &= dp.max_over_ranks(10.0 + rank, torch.device("cpu")) == 10.0 + world - 1
         q.put((rank, bool(ok)))
     finally:

@@ -1,0 +1,104 @@
+"""SURVEY section 8 rows A1 + N2 on the GPU: an Ultralytics-named state dict with non-trivial BatchNorm statistics ->
+convert_state_dict (BN folding) -> a VTIW1 file on disk -> `YOLO(path)` (the reference's entry point, measurement.py:145,
+config.py:67) -> `.predict(...)` through the HIP kernels, against an oracle that applies conv + BatchNorm2d(eps=1e-3)
+UNFUSED on the CPU.  Checks the folding, the container, the load path and that nc / nm / names come from the file."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from gpu_util import frames_u8, mask_iou, need_gpu
+from oracle.letterbox import letterbox
+from oracle.model import OracleModel
+from oracle.postproc import non_max_suppression, process_mask, scale_boxes
+from test_convert import fake_state_dict
+
+pytestmark = pytest.mark.gpu
+
+
+class UnfusedOracle(OracleModel):
+    """OracleModel whose Conv rows run conv (no bias) -> BatchNorm2d(eval, eps=1e-3) -> SiLU from the RAW state dict."""
+
+    def __init__(self, blob, sd, H, W):
+        super().__init__(blob, H, W, "fp32")
+        self.sd = sd
+
+    def conv(self, x, name, res=None, out_fp32=False):
+        w, b, k, s, kind = self.p[name]
+        if kind != 0:
+            return super().conv(x, name, res, out_fp32)
+        sd = self.sd
+        y = F.conv2d(x, sd[name + ".conv.weight"], None, stride=s, padding=k // 2)
+        y = F.batch_norm(y, sd[name + ".bn.running_mean"], sd[name + ".bn.running_var"], sd[name + ".bn.weight"],
+                         sd[name + ".bn.bias"], False, 0.0, 1e-3)
+        y = F.silu(y)
+        if res is not None:
+            y = res + y
+        if self.taps is not None:
+            self.taps[name] = y
+        return y
+
+
+def _scaled_state_dict(eng):
+    """fake_state_dict with conv weights scaled so that activations stay O(1) through the 76 layers under these BN statistics."""
+    sd = fake_state_dict(eng, seed=3)
+    for k in sd:
+        if k.endswith(".conv.weight"):
+            sd[k] = sd[k] * 1.6
+    return sd
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "fp16"])
+def test_yolo_path_runs_a_converted_checkpoint(tmp_path, dtype):
+    need_gpu()
+    import vti_amd
+    plan = vti_amd.Engine("n", 2, H=256, W=320, max_batch=1)            # the reference's model: 2 classes (config.py:69-70)
+    sd = _scaled_state_dict(plan)
+    blob = vti_amd.convert_state_dict(sd, plan)
+    path = tmp_path / "single_needle_model.vtiw"                        # config.py:67's file name, our container format
+    path.write_bytes(blob)
+
+    model = vti_amd.YOLO(str(path), dtype=dtype, names={0: "stitch", 1: "fabric"}, max_batch=2)
+    assert (model.scale, model.nc, model._nm, model._reg_max) == ("n", 2, 32, 16)       # read from the container, not passed in
+    assert model.names == {0: "stitch", 1: "fabric"}
+    frame = frames_u8(1, 240, 320, seed=77)[0]                          # letterboxed (auto) to 256 x 320
+    conf, iou, max_det = 0.5, 0.25, 200
+    r = model.predict(frame, verbose=False, conf=conf, iou=iou, max_det=max_det, imgsz=320)[0]
+    n = len(r.boxes)
+    assert n > 3 and r.masks is not None and r.masks.data.shape == (n, 256, 320)
+
+    lb, g = letterbox(frame, 320)
+    assert (g["H"], g["W"]) == (256, 320)
+    om = UnfusedOracle(blob, sd, 256, 320)
+    pred, proto = om.forward_u8(lb[None], swap_rb=True)
+    assert torch.isfinite(pred).all() and float(pred[0, 4:6].max()) > conf
+    eng = model._engine(256, 320, 1)
+    gp, gq = eng.forward(torch.from_numpy(lb[None]).cuda(), True)
+    e = (gp.cpu() - pred).abs()
+    if dtype == "fp32":
+        assert e[:, :4].max() < 5e-3 and e[:, 4:6].max() < 1e-4 and e[:, 6:].max() < 1e-3
+        assert (gq.float().cpu().permute(0, 3, 1, 2) - proto).abs().max() < 1e-3
+    else:           # fp16 storage of BN-folded weights and activations vs an fp32, unfused evaluation
+        assert e[:, 4:6].max() < 3e-2 and e[:, :4].max() < 4.0
+        return
+    det = non_max_suppression(pred.numpy(), conf, iou, max_det, nc=2)[0]
+    assert n == len(det)
+    xyxy = r.boxes.xyxy.cpu().numpy()
+    assert np.array_equal(r.boxes.cls.cpu().numpy(), det[:, 5])
+    assert np.abs(xyxy - scale_boxes((256, 320), det[:, :4], (240, 320))).max() < 5e-3
+    assert np.abs(r.boxes.conf.cpu().numpy() - det[:, 4]).max() < 1e-4
+    want = process_mask(proto[0], det[:, 6:], det[:, :4], (256, 320), "logit").numpy()
+    got = r.masks.data.cpu().numpy()
+    assert min(mask_iou(got[i], want[i]) for i in range(n)) >= 0.999
+
+
+def test_yolo_rejects_a_container_for_another_plan(tmp_path):
+    """A file whose conv table does not match its own header (here: truncated) must raise, not load garbage."""
+    need_gpu()
+    import vti_amd
+    plan = vti_amd.Engine("n", 2, H=64, W=64, max_batch=1)
+    blob = vti_amd.convert_state_dict(fake_state_dict(plan), plan)
+    p = tmp_path / "broken.vtiw"
+    p.write_bytes(blob[:-16])
+    with pytest.raises((vti_amd.VtiError, ValueError)):
+        vti_amd.YOLO(str(p)).predict(np.zeros((64, 64, 3), np.uint8))

@@ -208,8 +208,10 @@ def test_masks_dirty_oversized_buffer(dtype, packing):
     assert int(ref.sum()) > 0
 
 
-@pytest.mark.parametrize("H0,W0,imgsz", [(960, 1280, 960), (480, 640, 640), (333, 517, 640), (1080, 1920, 640), (640, 640, 640)])
+@pytest.mark.parametrize("H0,W0,imgsz", [(960, 1280, 960), (480, 640, 640), (333, 517, 640), (1080, 1920, 640), (640, 640, 640),
+                                           (1280, 1280, 640), (960, 1280, 640)])
 def test_letterbox_bit_exact(H0, W0, imgsz):
+    """(1280, 1280, 640) and (960, 1280, 640) are exact 2x downscales: OpenCV's INTER_LINEAR -> INTER_AREA substitution."""
     need_gpu()
     import vti_amd
     H, W = vti_amd.letterbox_shape(H0, W0, imgsz)

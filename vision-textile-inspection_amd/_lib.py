@@ -61,6 +61,10 @@ SIGNATURES = {
     "vti_mask_to_frame": (_I32, [_P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P]),
     "vti_union_envelope": (_I32, [_P, _P, _P, _I32, _I32, _I32, _P, _P, _P]),
     "vti_mask_stats": (_I32, [_P, _P, _I32, _I32, _I32, _P, _P]),
+    "vti_mask_stats_bits": (_I32, [_P, _P, _I32, _P, _I32, _I32, _I32, _I32, _P, _P]),
+    "vti_envelope_bits": (_I32, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P]),
+    "vti_pixels_to_world": (_I32, [_P, _P, _I32, _P, _P, _P, _P, _P, _P, _P]),
+    "vti_kmeans1d2": (_I32, [_P, _P, _P, _I32, _I32, _I32, _P, _P, _P]),
     "vti_debug_conv_output": (_I32, [_P, _I32, _I32, _P, _P]),
     "vti_debug_conv2d": (_I32, [_I32, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P, _I32, _I32, _I32, _I32,
                                 _P, _I32, _I32, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32,

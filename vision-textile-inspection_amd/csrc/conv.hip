@@ -546,7 +546,8 @@ hipError_t launch_stem_l1(int dtype, const ConvParams& p, hipStream_t st) {
     if (grid.x == 0) return hipSuccess;
     const size_t lds = stem_l1_lds_bytes(dtype);
     if (dtype == VTI_F16) {
-        static bool attr16 = false;
+        static bool attr16_dev[kMaxDevices] = {};
+        bool& attr16 = attr16_dev[current_device_slot()];
         if (!attr16) {
             hipError_t e = hipFuncSetAttribute((const void*)stem_l1_kernel<half_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return e;
@@ -554,7 +555,8 @@ hipError_t launch_stem_l1(int dtype, const ConvParams& p, hipStream_t st) {
         }
         hipLaunchKernelGGL(stem_l1_kernel<half_t>, grid, dim3(256), lds, st, p);
     } else {
-        static bool attr_done = false;
+        static bool attr_done_dev[kMaxDevices] = {};
+        bool& attr_done = attr_done_dev[current_device_slot()];
         if (!attr_done) {
             hipError_t e = hipFuncSetAttribute((const void*)stem_l1_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return e;
@@ -579,8 +581,9 @@ bool conv_cfg_fits(int ks, int stride, int mode, int TH, int TW, int WN, int NRE
 template <typename T, int KS, int S, int NREP, int WN, int NREP2 = 0>
 static hipError_t launch_one(const ConvParams& p, dim3 grid, size_t lds, hipStream_t st) {
     auto k = conv_kernel<T, KS, S, NREP, WN, NREP2>;
-    static size_t lds_ok = 64 * 1024;
-    if (lds > lds_ok) {
+    static size_t lds_ok_dev[kMaxDevices] = {};
+    size_t& lds_ok = lds_ok_dev[current_device_slot()];
+    if (lds > 64 * 1024 && lds > lds_ok) {
         hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         lds_ok = 160 * 1024;

@@ -590,7 +590,8 @@ __global__ __launch_bounds__(512) void conv1_pk(const ConvParams p) {
 template <typename T, int NREP, int WN, int NREP2 = 0>
 static hipError_t launch_pk_one(const ConvParams& p, dim3 grid, int threads, size_t lds, hipStream_t st) {
     auto k = conv3_pk<T, NREP, WN, NREP2>;
-    static bool attr_done = false;
+    static bool attr_done_dev[kMaxDevices] = {};
+    bool& attr_done = attr_done_dev[current_device_slot()];
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
@@ -622,7 +623,8 @@ bool conv_pk_instantiated(int nrep, int wn) {
 template <typename T, int NREP, int WN>
 static hipError_t launch_pk1_one(const ConvParams& p, dim3 grid, int threads, size_t lds, hipStream_t st) {
     auto k = conv1_pk<T, NREP, WN>;
-    static bool attr_done = false;
+    static bool attr_done_dev[kMaxDevices] = {};
+    bool& attr_done = attr_done_dev[current_device_slot()];
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;

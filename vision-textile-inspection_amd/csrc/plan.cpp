@@ -522,12 +522,20 @@ std::string Plan::build(const vti_desc& d) {
         if (op.kind != OP_CONV && op.kind != OP_CONV0) continue;
         const ConvRow& r = convs[op.conv];
         macs += r.macs(); fused_params += r.fused_params();
+        // The persistent kernels address whole tensors through ONE buffer resource with 32-bit offsets and use bit 31 as the
+        // "out of range" marker, so a tensor of 2 GiB or more (at max_batch) keeps its convs on the per-tile kernel, which makes a
+        // resource per frame.  Decided here, at plan time, so that nothing downstream (the folded Upsample) relies on a kernel
+        // the run-time size check would refuse.  VTI_PK_LIMIT_BYTES lowers the limit (tests of this fall-back).
+        size_t pk_limit = 0x80000000ull;
+        if (const char* pl = getenv("VTI_PK_LIMIT_BYTES")) pk_limit = (size_t)atoll(pl);
+        const bool pk_ok = bufs[op.in.buf].bytes < pk_limit && bufs[op.out.buf].bytes < pk_limit &&
+                           (!op.has_res || bufs[op.res.buf].bytes < pk_limit);
         if (op.fused_l1 >= 0) choose_conv_cfg(d.dtype, r, true, d.max_batch, op.cfg, 0, 0, 1, 1);   // one 16-channel n-tile: stem_l1_kernel's weight indexing
         else if (op.fused >= 0) {   // whole Cout in one wave; the per-tile kernel (2 workgroups per CU) hides the long fused epilogue better
             const char* pf = getenv("VTI_PK_FUSED");
-            choose_conv_cfg(d.dtype, r, false, d.max_batch, op.cfg, 0, 0, 1, r.c2 / 16, pf && pf[0] == '1');
+            choose_conv_cfg(d.dtype, r, false, d.max_batch, op.cfg, 0, 0, 1, r.c2 / 16, pk_ok && pf && pf[0] == '1');
         }
-        else choose_conv_cfg(d.dtype, r, op.kind == OP_CONV0, d.max_batch, op.cfg);
+        else choose_conv_cfg(d.dtype, r, op.kind == OP_CONV0, d.max_batch, op.cfg, 0, 0, 0, 0, pk_ok);
         if (op.cfg.TH == 0) return "no launch configuration for conv " + r.name;
         op.nat2 = (op.fused >= 0 && op.fused_l1 < 0 && (op.pred_mode || op.out2_f32)) ? 1 : 0;
         op.cfg.wpk_off = woff;

@@ -53,6 +53,9 @@ __global__ __launch_bounds__(256) void letterbox_kernel(const uint8_t* __restric
     const double scale_x = 1.0 / ((double)new_w / (double)W0);
     const double scale_y = 1.0 / ((double)new_h / (double)H0);
     const bool resize = (new_w != W0) || (new_h != H0);
+    // OpenCV's resize() turns INTER_LINEAR into INTER_AREA when both scales are exactly 2 (hal::resize: is_area_fast &&
+    // iscale_x == 2 && iscale_y == 2): the u8 result is the rounded 2x2 box mean, not the bilinear tap pair
+    const bool area2 = W0 == 2 * new_w && H0 == 2 * new_h;
     for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const int x = (int)(i % W);
         long r = i / W;
@@ -68,6 +71,13 @@ __global__ __launch_bounds__(256) void letterbox_kernel(const uint8_t* __restric
         if (!resize) {
             const uint8_t* s = src + ((size_t)dy * W0 + dx) * 3;
             o[0] = s[0]; o[1] = s[1]; o[2] = s[2];
+            continue;
+        }
+        if (area2) {
+            const uint8_t* s0 = src + ((size_t)(2 * dy) * W0 + 2 * dx) * 3;
+            const uint8_t* s1 = s0 + (size_t)W0 * 3;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) o[c] = (uint8_t)((s0[c] + s0[3 + c] + s1[c] + s1[3 + c] + 2) >> 2);
             continue;
         }
         const LinTap tx = lin_tap(dx, W0, scale_x, true);
@@ -101,6 +111,7 @@ constexpr int NMS_THREADS = 512;
 constexpr int NMS_LDS_BOX = 2048;         // sorted boxes/areas/keep list live in LDS up to this many candidates
 constexpr int NMS_LDS_KEYS = 2048;        // == NMS_LDS_BOX: beyond this many candidates everything lives in global scratch
 constexpr float NMS_MAX_WH = 7680.0f;     // Ultralytics class offset
+constexpr int NMS_MAX_NMS = 30000;        // Ultralytics max_nms: only the 30000 best-scoring candidates enter the greedy pass
 
 static inline size_t nms_pow2(size_t n) { size_t p = 1; while (p < n) p <<= 1; return p; }
 static inline size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
@@ -235,6 +246,9 @@ __device__ __forceinline__ void nms_body(const float* __restrict__ P, int A, int
         }
     }
     NMS_STAMP(1);
+    // Ultralytics: `x = x[x[:, 4].argsort(descending=True)[:max_nms]]` -- the keys are already in that order
+    // (reachable only with more than 30000 anchors, e.g. 1280x1280 inputs: A = 33600)
+    if (n > NMS_MAX_NMS) n = NMS_MAX_NMS;
     // 3. boxes in sorted order: xywh -> xyxy, + class offset, areas (all fp32 as torch computes them)
     for (int i = tid; i < n; i += NMS_THREADS) {
         const int a = (int)(keys[i] & 0xffffffffu);
@@ -432,7 +446,8 @@ hipError_t launch_nms(const float* pred, int B, int A, int nc, int nm, float con
     if (B == 0) return hipSuccess;
     const size_t lds = (size_t)NMS_LDS_KEYS * 8 + (size_t)NMS_LDS_BOX * 32 + (((size_t)A + 15) & ~(size_t)15);
     if (lds > 150 * 1024) return hipErrorInvalidValue;   // > ~39k anchors: unsupported
-    static bool attr_set = false;
+    static bool attr_set_dev[kMaxDevices] = {};
+    bool& attr_set = attr_set_dev[current_device_slot()];
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         if (e != hipSuccess) return e;
@@ -813,7 +828,8 @@ hipError_t launch_masks(int dtype, const float* dets, const int* counts, const v
                        capacity, items, nitems, csplit);
     // persistent blocks walk the work list: exactly as many as are resident at once (a second round of late blocks would run
     // on a mostly empty chip), a multiple of 8 for the per-XCD partition
-    static int per_cu[4] = {0, 0, 0, 0};
+    static int per_cu_dev[kMaxDevices][4] = {};
+    int* per_cu = per_cu_dev[current_device_slot()];
     const int kidx = (dtype == VTI_F16 ? 0 : 2) + (nm == 32 ? 0 : 1);
     if (!per_cu[kidx]) {
         int nb = 0;

@@ -35,7 +35,7 @@ struct vti_ctx {
 };
 
 static std::string g_create_err;
-static const int kMaskSlotsPerFrame = 512;   // mask work-list capacity: max_batch * 512 instances per call
+static const int kMaskSlotsPerFrame = VTI_MASK_SLOTS_PER_FRAME;   // mask work-list capacity: max_batch * 512 instances per call
 
 static int32_t fail(vti_ctx* c, int32_t code, const std::string& msg) {
     if (c) c->err = msg; else g_create_err = msg;
@@ -182,8 +182,20 @@ int32_t vti_set_workspace(vti_ctx* c, void* dev_ws, size_t nbytes) {
     return VTI_OK;
 }
 
+// A ctx is bound to the device its weights were uploaded to (vti_load_weights); every launching entry point refuses to run
+// with another device current instead of launching there with pointers of the wrong GPU.
+static int32_t check_device(vti_ctx* c, const char* fn) {
+    if (!c || c->device < 0) return VTI_OK;
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != c->device)
+        return fail(c, VTI_ERR_STATE, std::string(fn) + ": ctx is bound to device " + std::to_string(c->device) +
+                    " but the current device is " + std::to_string(cur) + " (hipSetDevice / torch.cuda.set_device it first)");
+    return VTI_OK;
+}
+
 static int32_t check_ready(vti_ctx* c, int32_t B, const char* fn) {
     if (!c) return VTI_ERR_ARG;
+    if (int32_t rc = check_device(c, fn)) return rc;
     if (B < 0 || B > c->plan.desc.max_batch) return fail(c, VTI_ERR_ARG, std::string(fn) + ": B out of range (0..max_batch)");
     if (!c->d_wpk) return fail(c, VTI_ERR_STATE, std::string(fn) + ": weights not loaded");
     if (!c->ws) return fail(c, VTI_ERR_STATE, std::string(fn) + ": workspace not set");
@@ -204,6 +216,7 @@ int32_t vti_letterbox(vti_ctx* c, const uint8_t* frames, int32_t B, int32_t H0, 
     if (!c || !frames || !out || H0 < 1 || W0 < 1 || B < 0) return fail(c, VTI_ERR_ARG, "vti_letterbox: bad argument");
     int nh, nw, top, left;
     letterbox_geom(H0, W0, c->plan.desc.H, c->plan.desc.W, nh, nw, top, left);
+    if (int32_t drc = check_device(c, "vti_letterbox")) return drc;
     VTI_HIP(c, launch_letterbox(frames, B, H0, W0, out, c->plan.desc.H, c->plan.desc.W, nh, nw, top, left, (hipStream_t)stream),
             "letterbox kernel");
     return VTI_OK;
@@ -466,6 +479,7 @@ int32_t vti_nms(vti_ctx* c, const float* pred, int32_t B, float conf, double iou
     if (B < 0 || B > c->plan.desc.max_batch) return fail(c, VTI_ERR_ARG, "vti_nms: B out of range");
     if (!c->ws) return fail(c, VTI_ERR_STATE, "vti_nms: workspace not set");
     if (!pred || !dets || !counts || max_det < 1) return fail(c, VTI_ERR_ARG, "vti_nms: bad argument");
+    if (int32_t drc = check_device(c, "vti_nms")) return drc;
     VTI_HIP(c, launch_nms(pred, B, c->plan.num_anchors, c->plan.desc.nc, c->plan.desc.nm, conf, iou, max_det, agnostic,
                           dets, counts, c->ws + c->act_bytes, (hipStream_t)stream), "nms kernel");
     return VTI_OK;
@@ -483,6 +497,7 @@ int32_t vti_masks(vti_ctx* c, const float* dets, const int32_t* counts, const vo
     if (capacity > d.max_batch * kMaskSlotsPerFrame)
         return fail(c, VTI_ERR_UNSUPPORTED, "vti_masks: capacity above max_batch*512 instances per call");
     void* mws = c->ws + c->act_bytes + nms_workspace_bytes(d.max_batch, c->plan.num_anchors);
+    if (int32_t drc = check_device(c, "vti_masks")) return drc;
     VTI_HIP(c, launch_masks(d.dtype, dets, counts, proto, B, max_det, d.nm, d.H / 4, d.W / 4, d.H, d.W, mode, packing, masks,
                             capacity, offsets, mws, (hipStream_t)stream), "mask kernel");
     return VTI_OK;
@@ -493,6 +508,7 @@ int32_t vti_scale_boxes(vti_ctx* c, const float* dets, const int32_t* counts, in
     if (!c || !dets || !counts || !xyxy || B < 0 || max_det < 1 || H0 < 1 || W0 < 1)
         return fail(c, VTI_ERR_ARG, "vti_scale_boxes: bad argument");
     const vti_desc& d = c->plan.desc;
+    if (int32_t drc = check_device(c, "vti_scale_boxes")) return drc;
     VTI_HIP(c, launch_scale_boxes(dets, counts, B, max_det, d.nm, d.H, d.W, H0, W0, xyxy, (hipStream_t)stream), "scale_boxes kernel");
     return VTI_OK;
 }
@@ -522,6 +538,7 @@ int32_t vti_mask_to_frame(vti_ctx* c, const uint8_t* masks, int32_t n, int32_t H
                           uint8_t* bitmaps, int32_t* nonzero, void* stream) {
     if (!c || n < 0 || H < 1 || W < 1 || H0 < 1 || W0 < 1 || (n && (!masks || !bitmaps || !nonzero)))
         return fail(c, VTI_ERR_ARG, "vti_mask_to_frame: bad argument");
+    if (int32_t drc = check_device(c, "vti_mask_to_frame")) return drc;
     VTI_HIP(c, launch_mask_to_frame(masks, n, H, W, H0, W0, bitmaps, nonzero, (hipStream_t)stream), "mask_to_frame kernel");
     return VTI_OK;
 }
@@ -530,6 +547,7 @@ int32_t vti_union_envelope(vti_ctx* c, const uint8_t* bitmaps, const int32_t* se
                            uint8_t* uni, int32_t* envelope, void* stream) {
     if (!c || nsel < 0 || H0 < 1 || W0 < 1 || !uni || !envelope || (nsel && (!bitmaps || !select)))
         return fail(c, VTI_ERR_ARG, "vti_union_envelope: bad argument");
+    if (int32_t drc = check_device(c, "vti_union_envelope")) return drc;
     VTI_HIP(c, launch_union_envelope(bitmaps, select, nsel, H0, W0, uni, envelope, (hipStream_t)stream), "union_envelope kernel");
     return VTI_OK;
 }
@@ -537,7 +555,44 @@ int32_t vti_union_envelope(vti_ctx* c, const uint8_t* bitmaps, const int32_t* se
 int32_t vti_mask_stats(vti_ctx* c, const uint8_t* bitmaps, int32_t n, int32_t H0, int32_t W0, int64_t* stats, void* stream) {
     if (!c || n < 0 || H0 < 1 || W0 < 1 || (n && (!bitmaps || !stats)))
         return fail(c, VTI_ERR_ARG, "vti_mask_stats: bad argument");
+    if (int32_t drc = check_device(c, "vti_mask_stats")) return drc;
     VTI_HIP(c, launch_mask_stats(bitmaps, n, H0, W0, (long long*)stats, (hipStream_t)stream), "mask_stats kernel");
+    return VTI_OK;
+}
+
+int32_t vti_mask_stats_bits(vti_ctx* c, const uint8_t* masks_bits, int32_t n, const int32_t* n_live, int32_t H, int32_t W,
+                            int32_t H0, int32_t W0, int64_t* stats, void* stream) {
+    if (n < 0 || H < 1 || W < 32 || (W & 31) || H0 < 1 || W0 < 1 || (n && (!masks_bits || !stats)))
+        return fail(c, VTI_ERR_ARG, "vti_mask_stats_bits: bad argument (W must be a multiple of 32)");
+    if (int32_t drc = check_device(c, "vti_mask_stats_bits")) return drc;
+    VTI_HIP(c, launch_mask_stats_bits(masks_bits, n, n_live, H, W, H0, W0, (long long*)stats, (hipStream_t)stream), "mask_stats_bits kernel");
+    return VTI_OK;
+}
+
+int32_t vti_envelope_bits(vti_ctx* c, const uint8_t* masks_bits, const int32_t* offsets, const float* dets, int32_t B,
+                          int32_t max_det, int32_t capacity, int32_t cls, int32_t H0, int32_t W0, int32_t* envelope, void* stream) {
+    if (!c || B < 0 || max_det < 1 || capacity < 0 || H0 < 1 || W0 < 1 || (B && (!masks_bits || !offsets || !dets || !envelope)))
+        return fail(c, VTI_ERR_ARG, "vti_envelope_bits: bad argument");
+    const vti_desc& d = c->plan.desc;
+    if (int32_t drc = check_device(c, "vti_envelope_bits")) return drc;
+    VTI_HIP(c, launch_envelope_bits(masks_bits, offsets, dets, B, max_det, d.nm, capacity, cls, d.H, d.W, H0, W0, envelope,
+                                    (hipStream_t)stream), "envelope_bits kernel");
+    return VTI_OK;
+}
+
+int32_t vti_pixels_to_world(vti_ctx* c, const double* uv, int32_t n, const double* K, const double* dist, const double* R,
+                            const double* t, double* xyz, int32_t* valid, void* stream) {
+    if (n < 0 || !K || !dist || !R || !t || (n && (!uv || !xyz || !valid)))
+        return fail(c, VTI_ERR_ARG, "vti_pixels_to_world: bad argument");
+    VTI_HIP(c, launch_pixels_to_world(uv, n, K, dist, R, t, xyz, valid, (hipStream_t)stream), "pixels_to_world kernel");
+    return VTI_OK;
+}
+
+int32_t vti_kmeans1d2(vti_ctx* c, const double* values, const int32_t* counts, int32_t B, int32_t max_n, int32_t max_iters,
+                      int32_t* labels, double* centers, void* stream) {
+    if (B < 0 || max_n < 1 || max_n > 1024 || max_iters < 0 || (B && (!values || !counts || !labels || !centers)))
+        return fail(c, VTI_ERR_ARG, "vti_kmeans1d2: bad argument (max_n <= 1024)");
+    VTI_HIP(c, launch_kmeans1d2(values, counts, B, max_n, max_iters, labels, centers, (hipStream_t)stream), "kmeans1d2 kernel");
     return VTI_OK;
 }
 

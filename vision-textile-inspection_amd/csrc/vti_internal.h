@@ -11,6 +11,11 @@
 
 namespace vti {
 
+// hipFuncSetAttribute (the > 64 KB dynamic-LDS opt-in) is a per-device setting: the "already done" flags of the launchers are kept
+// per device, so a process that holds contexts on several GPUs sets it on each of them.
+constexpr int kMaxDevices = 64;
+inline int current_device_slot() { int d = 0; (void)hipGetDevice(&d); return (unsigned)d < (unsigned)kMaxDevices ? d : 0; }
+
 // ---- plan ---------------------------------------------------------------------------
 enum ElemKind { EL_T = 0, EL_F32 = 1, EL_U8 = 2 };   // EL_T = ctx dtype (fp16 or fp32)
 
@@ -179,6 +184,16 @@ hipError_t launch_mask_to_frame(const uint8_t* masks, int n, int H, int W, int H
 hipError_t launch_union_envelope(const uint8_t* bitmaps, const int* select, int nsel, int H0, int W0,
                                  uint8_t* uni, int* envelope, hipStream_t st);
 hipError_t launch_mask_stats(const uint8_t* bitmaps, int n, int H0, int W0, long long* stats, hipStream_t st);
+
+// consumer.hip: reductions on bit-packed masks, pixel -> world geometry, 1-D 2-means
+hipError_t launch_mask_stats_bits(const uint8_t* bits, int n, const int* n_live, int H, int W, int H0, int W0, long long* stats,
+                                  hipStream_t st);
+hipError_t launch_envelope_bits(const uint8_t* bits, const int* offsets, const float* dets, int B, int max_det, int nm,
+                                int capacity, int cls, int H, int W, int H0, int W0, int* envelope, hipStream_t st);
+hipError_t launch_pixels_to_world(const double* uv, int n, const double* K, const double* dist, const double* R,
+                                  const double* t, double* xyz, int* valid, hipStream_t st);
+hipError_t launch_kmeans1d2(const double* values, const int* counts, int B, int max_n, int max_iters, int* labels,
+                            double* centers, hipStream_t st);
 
 // plan.cpp: launch geometry for one conv (tile, wave split, LDS) -- th/tw/wn/nrep > 0 force a choice
 void choose_conv_cfg(int dtype, const ConvRow& r, bool conv0, int max_batch, ConvCfg& c,

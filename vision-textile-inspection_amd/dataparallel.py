@@ -44,13 +44,49 @@ def gather_tensor(t, dst=0, group=None):
     return None
 
 
-def gather_detections(out, dst=0, group=None):
-    """Gather one predict_into() output set: dets f32 [b,max_det,6+nm], counts i32 [b], xyxy f32
-    [b,max_det,4] and the fixed-capacity bit-packed masks + per-rank offsets.  Root gets a dict of
-    concatenated tensors (mask slots of rank r start at r*capacity), others None."""
-    keys = ("dets", "counts", "xyxy", "masks", "offsets")
+COMPACT_KEYS = ("dets", "counts", "xyxy", "offsets", "stats", "envelope")
+
+
+def gather_detections(out, dst=0, group=None, keys=None):
+    """Gather what the consumer needs from one predict_into() output set: dets f32 [b,max_det,6+nm], counts i32 [b], xyxy f32
+    [b,max_det,4], offsets i32 [b+1] and -- when the caller computed them (Engine.mask_stats_bits / envelope_bits: SURVEY 8
+    row N1) -- stats i64 [capacity,5] and envelope i32 [b,W0]: a few MB per rank instead of the mask buffer (capacity x H x W/8
+    bytes: 210 MB per rank at 64 frames of 640x640, most of it dead slots).  Root gets a dict of concatenated tensors, others
+    None.  Masks themselves travel through gather_live_masks when a consumer really wants the bitmaps."""
+    keys = [k for k in (keys or COMPACT_KEYS) if k in out and out[k] is not None]
     got = {k: gather_tensor(out[k], dst, group) for k in keys}
     return got if dist.get_rank(group) == dst else None
+
+
+def gather_live_masks(masks, offsets, dst=0, group=None):
+    """Variable-length gather of the LIVE mask slots only: rank r sends masks[:offsets[-1]] (its instances), not its whole
+    fixed-capacity buffer.  Sizes are exchanged first (one small all_gather, one host read per rank), then every peer sends
+    exactly its live slots point to point -- 7 distinct xGMI links into the root.  Root returns (masks [sum_live, ...],
+    live i64 [world]) with rank r's slots at [live[:r].sum(), live[:r+1].sum()); others None."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    n_live = offsets[-1:].to(torch.int64).clamp(max=masks.shape[0])
+    sizes = [torch.zeros_like(n_live) for _ in range(world)]
+    dist.all_gather(sizes, n_live, group=group)
+    live = torch.cat(sizes).cpu()
+    if rank == dst:
+        total = int(live.sum())
+        buf = torch.empty((total, *masks.shape[1:]), dtype=masks.dtype, device=masks.device)
+        reqs, at = [], 0
+        for r in range(world):
+            n = int(live[r])
+            if r == dst:
+                buf[at:at + n].copy_(masks[:n])
+            elif n:
+                reqs.append(dist.irecv(buf[at:at + n], src=r, group=group))
+            at += n
+        for q in reqs:
+            q.wait()
+        return buf, live
+    n = int(live[rank])
+    if n:
+        dist.send(masks[:n].contiguous(), dst=dst, group=group)
+    return None
 
 
 def max_over_ranks(value, device, group=None):

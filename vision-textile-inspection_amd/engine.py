@@ -223,6 +223,28 @@ class Engine:
         check(self._ctx, lib().vti_mask_stats(self._ctx, _ptr(bitmaps), n, H0, W0, _ptr(stats), _stream()))
         return stats
 
+    # ---- the same reductions straight from bit-packed masks (no frame-sized bitmaps) ------
+    def mask_stats_bits(self, masks_bits, H0, W0, stats=None, offsets=None):
+        """masks_bits u8 [n,H,W/8] (VTI_PACK_BITS) -> i64 [n,5] = m00, m10, m01, min_col, max_col of each instance's
+        H0 x W0 nearest-resized bitmap (measurement.py:70-86,302-318).  `offsets` (i32 [B+1] from masks()): slots at and
+        beyond offsets[B] of a fixed-capacity buffer are skipped and report the empty mask."""
+        n, H, wb = masks_bits.shape
+        if stats is None:
+            stats = torch.empty((n, 5), dtype=torch.int64, device=masks_bits.device)
+        n_live = C.c_void_p(offsets.data_ptr() + 4 * (offsets.numel() - 1)) if offsets is not None else C.c_void_p(0)
+        check(self._ctx, lib().vti_mask_stats_bits(self._ctx, _ptr(masks_bits), n, n_live, H, wb * 8, H0, W0, _ptr(stats), _stream()))
+        return stats
+
+    def envelope_bits(self, masks_bits, offsets, dets, cls, H0, W0, envelope=None):
+        """Per frame: lower envelope i32 [B,W0] of the union of its instances of class `cls` (< 0: all)
+        (measurement.py:160-185 on the bitmaps of measurement.py:70-86)."""
+        B, max_det = dets.shape[0], dets.shape[1]
+        if envelope is None:
+            envelope = torch.empty((B, W0), dtype=torch.int32, device=dets.device)
+        check(self._ctx, lib().vti_envelope_bits(self._ctx, _ptr(masks_bits), _ptr(offsets), _ptr(dets), B, max_det,
+                                                 masks_bits.shape[0], int(cls), H0, W0, _ptr(envelope), _stream()))
+        return envelope
+
     # ---- test hook ---------------------------------------------------------------------
     def debug_conv_output(self, i, B):
         t = self.conv_table()[i]
@@ -237,6 +259,37 @@ class Engine:
             raise ValueError("input must be a contiguous device tensor")
         if t.shape[0] > self.max_batch:
             raise ValueError(f"batch {t.shape[0]} exceeds max_batch {self.max_batch}")
+
+
+def _f64(a, n):
+    a = np.ascontiguousarray(np.asarray(a, dtype=np.float64).ravel())
+    if a.size != n:
+        raise ValueError(f"expected {n} float64 values, got {a.size}")
+    return a
+
+
+def pixels_to_world(uv, K, dist, R, t):
+    """measurement.py:50-65 for n points at once.  uv f64 [n,2] device tensor; K (3x3), dist (5), R (3x3), t (3) host arrays.
+    -> (xyz f64 [n,3] device, valid i32 [n])."""
+    uv = uv.to(torch.float64).contiguous()
+    n = uv.shape[0]
+    xyz = torch.empty((n, 3), dtype=torch.float64, device=uv.device)
+    valid = torch.empty((n,), dtype=torch.int32, device=uv.device)
+    Kh, dh, Rh, th = _f64(K, 9), _f64(dist, 5), _f64(R, 9), _f64(t, 3)
+    rc = lib().vti_pixels_to_world(None, _ptr(uv), n, Kh.ctypes.data_as(C.c_void_p), dh.ctypes.data_as(C.c_void_p),
+                                   Rh.ctypes.data_as(C.c_void_p), th.ctypes.data_as(C.c_void_p), _ptr(xyz), _ptr(valid), _stream())
+    check(None, rc)
+    return xyz, valid
+
+
+def kmeans1d2(values, counts, max_iters=10):
+    """measurement.py:88-113 batched.  values f64 [B,max_n] device, counts i32 [B] -> (labels i32 [B,max_n], centers f64 [B,2])."""
+    values = values.to(torch.float64).contiguous()
+    B, max_n = values.shape
+    labels = torch.empty((B, max_n), dtype=torch.int32, device=values.device)
+    centers = torch.empty((B, 2), dtype=torch.float64, device=values.device)
+    check(None, lib().vti_kmeans1d2(None, _ptr(values), _ptr(counts), B, max_n, int(max_iters), _ptr(labels), _ptr(centers), _stream()))
+    return labels, centers
 
 
 def unpack_bits(bits, W):

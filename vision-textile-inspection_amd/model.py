@@ -22,6 +22,7 @@ from .weights import random_weights, unpack_container
 def letterbox_shape(H0, W0, imgsz, auto=True, stride=32):
     """Ultralytics LetterBox output size."""
     new_shape = (imgsz, imgsz) if isinstance(imgsz, int) else tuple(imgsz)
+    new_shape = tuple(max(math.ceil(x / stride) * stride, stride) for x in new_shape)   # Ultralytics check_imgsz: round up to the stride
     r = min(new_shape[0] / H0, new_shape[1] / W0)
     new_w, new_h = int(round(W0 * r)), int(round(H0 * r))
     dw, dh = new_shape[1] - new_w, new_shape[0] - new_h
@@ -57,12 +58,21 @@ class Boxes:
 
 
 class Masks:
-    """Results.masks: `.data` is f32 0/1 [N,H,W] at the LETTERBOXED size, as Ultralytics returns it."""
+    """Results.masks: `.data` is f32 0/1 [N,H,W] at the LETTERBOXED size, as Ultralytics returns it.  The engine writes
+    bit-packed masks (u8 [N,H,W/8]); they are expanded on the device the first time `.data` / `.data_u8` is read."""
 
-    def __init__(self, data_u8, orig_shape):
-        self.data_u8 = data_u8           # u8 [N,H,W] device tensor (0/1)
+    def __init__(self, bits, W, orig_shape):
+        self.bits = bits                 # u8 [N,H,W/8] device tensor, LSB-first
+        self._W = W
         self.orig_shape = orig_shape
+        self._u8 = None
         self._f = None
+
+    @property
+    def data_u8(self):
+        if self._u8 is None:
+            self._u8 = unpack_bits(self.bits, self._W)
+        return self._u8
 
     @property
     def data(self):
@@ -75,7 +85,7 @@ class Masks:
         raise NotImplementedError("polygon masks (.xy) are not produced; use .data")
 
     def __len__(self):
-        return self.data_u8.shape[0]
+        return self.bits.shape[0]
 
 
 class Results:
@@ -116,11 +126,14 @@ class YOLO:
         self.names = names if names is not None else {i: f"class{i}" for i in range(nc)}
         self._engines = {}
 
-    def _engine(self, H, W, B):
+    def _engine(self, H, W, B, max_det=300):
         key = (H, W)
         eng = self._engines.get(key)
-        if eng is None or eng.max_batch < B:
-            eng = Engine(self.scale, self.nc, self._nm, self._reg_max, H, W, max(B, 1), self.dtype)
+        # one vti_masks call handles max_batch * 512 instances (VTI_MASK_SLOTS_PER_FRAME): a predict() with a larger max_det
+        # gets an engine with proportionally more batch slots, so every detection still gets its mask
+        need = max(B, -(-B * max_det // 512), 1)
+        if eng is None or eng.max_batch < need:
+            eng = Engine(self.scale, self.nc, self._nm, self._reg_max, H, W, need, self.dtype)
             if self._blob is None:
                 self._blob = random_weights(eng, self._seed, self._cls_bias)
             eng.load_weights(self._blob, self.device)
@@ -151,20 +164,22 @@ class YOLO:
         frames = self._to_device_batch(source)
         B, H0, W0, _ = frames.shape
         H, W = letterbox_shape(H0, W0, imgsz)
-        eng = self._engine(H, W, B)
-        inp = frames if (H0, W0) == (H, W) else eng.letterbox(frames)
-        pred, proto = eng.forward(inp, swap_rb)
-        dets, counts = eng.nms(pred, conf, iou, max_det, agnostic_nms)
-        masks, offsets = eng.masks(dets, counts, proto, self.mask_mode, "u8")
-        xyxy = eng.scale_boxes(dets, counts, H0, W0)
-        cnt = counts.cpu().tolist()
-        off = offsets.cpu().tolist()
+        eng = self._engine(H, W, B, max_det)
+        # the whole pipeline is enqueued without a host read in between (vti_predict: letterbox -> net -> NMS -> bit-packed
+        # masks for up to B * max_det instances -> scale_boxes); the counts are read once, at the end, to cut the Results
+        o = eng.alloc_outputs(B, max_det, B * max_det, "bits", frames.device)
+        eng.predict_into(frames, o, conf, iou, max_det, agnostic_nms, swap_rb, self.mask_mode, "bits")
+        dets, xyxy, masks = o["dets"], o["xyxy"], o["masks"]
+        cnt = o["counts"].cpu().tolist()
+        off = o["offsets"].cpu().tolist()
         out = []
         for b in range(B):
             n = cnt[b]
             data = torch.cat((xyxy[b, :n], dets[b, :n, 4:6]), 1)
-            m = Masks(masks[off[b]:off[b] + n], (H0, W0)) if n else None
-            out.append(Results((H0, W0), self.names, Boxes(data, (H0, W0)), m, dets[b, :n]))
+            m = Masks(masks[off[b]:off[b] + n], W, (H0, W0)) if n else None
+            r = Results((H0, W0), self.names, Boxes(data, (H0, W0)), m, dets[b, :n])
+            r._engine = eng
+            out.append(r)
         return out
 
     __call__ = predict
