@@ -200,6 +200,174 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvParams p) {   //
     VTI_STAMP(12);
 }
 
+// ---- ConvTranspose2d(C, C, 2, 2) folded into the 3x3 conv that follows it, with that conv's fused 1x1 stage
+// (proto.upsample -> proto.cv2 -> proto.cv3; algebra and weight composition: weights.cpp, pack_conv_fold).
+// A workgroup owns a TH x TW tile of the LOW-resolution map (<= 80 pixels) and stages its (TH+2) x (TW+2) patch exactly as the
+// 3x3 kernel does; wave w is output PHASE (py, px) = (w >> 1, w & 1): it computes the 64 mid channels of output pixels
+// (2y+py, 2x+px) for all the tile's (y, x) as a 2x2 conv whose window starts at patch row py, column px -- 4 taps x C deep
+// instead of 9 taps x C at 4x the pixels -- and then runs the 1x1 stage on its register tile (conv_stage2<FOLD>).
+// ConvParams: in/Hin/Win/Cin = the deconv's input; Hout/Wout = Hin/Win (tile grid); wpk = [chunk][16 n-tiles: phase-major][4 taps]
+// fragments; bias = [3][3][64] border-class table; w2/bias2/out2 = the fused 1x1 on the 2Hout x 2Wout grid.
+size_t convfold_lds_bytes(int TH, int TW) {
+    const int npix = (TH + 2) * (TW + 2);
+    return 4 * (size_t)((npix + 15) & ~15) * 16 + (size_t)16 * 4 * 1024;
+}
+bool convfold_supported(int c_in, int c_mid, int c_out, int ntiles2) {
+    return c_in == c_mid && c_mid % 16 == 0 && c_out == 64 && c_in % 16 == 0 && c_in <= 64 && (ntiles2 == 1 || ntiles2 == 2 || ntiles2 == 4);
+}
+
+template <typename T, int NREP2>
+__global__ __launch_bounds__(256, 2) void convfold_kernel(const ConvParams p) {
+    using vec = typename Tr<T>::vec;
+    constexpr int VEC = Tr<T>::VEC, KC = Tr<T>::KC;
+    constexpr int NREP = 4, TAPS = 4, NTB = 16, AR = 8;
+    constexpr int BR = NTB * TAPS * 64 / 256;                 // 16 weight pieces per thread and chunk
+    constexpr unsigned OOB = 0xFFFFFFFFu;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int py = wave >> 1, px = wave & 1;
+    int t = blockIdx.x;
+    const int tx = t % p.tiles_x; t /= p.tiles_x;
+    const int ty = t % p.tiles_y;
+    const int b = t / p.tiles_y;
+    const int oy0 = ty * p.TH, ox0 = tx * p.TW;                // low-resolution tile origin
+    const int PH = p.TH + 2, PW = p.TW + 2;
+    const int npix = PH * PW;
+    const int plane_bytes = ((npix + 15) & ~15) * 16;
+    char* smA = smem;
+    char* smB = smem + 4 * plane_bytes;
+    const int tile_px = p.TH * p.TW;
+
+    int abase[MREP], opy[MREP], opx[MREP];
+    bool pvalid[MREP];
+#pragma unroll
+    for (int m = 0; m < MREP; ++m) {
+        const int pp = m * 16 + (lane & 15);
+        const bool v = pp < tile_px;
+        const int pc = v ? pp : 0;
+        const int ly = (int)__umulhi((unsigned)pc, p.tw_magic), lx = pc - ly * p.TW;
+        pvalid[m] = v && oy0 + ly < p.Hout && ox0 + lx < p.Wout;
+        opy[m] = 2 * (oy0 + ly) + py; opx[m] = 2 * (ox0 + lx) + px;         // this wave's output pixel of low-res pixel (ly, lx)
+        abase[m] = (lane >> 4) * plane_bytes + ((ly + py) * PW + lx + px) * 16;   // window origin: patch (ly + py, lx + px)
+    }
+    f32x4 acc[MREP][NREP];
+#pragma unroll
+    for (int m = 0; m < MREP; ++m)
+#pragma unroll
+        for (int n = 0; n < NREP; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const size_t frame_elems = (size_t)p.Hin * p.Win * p.in_ld;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((const T*)p.in + (size_t)b * frame_elems), 0, (int)(frame_elems * sizeof(T)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.wpk, 0, (int)p.wpk_bytes, 0x00020000);
+    const int iy0 = oy0 - 1, ix0 = ox0 - 1;
+    const int q = (tid >> 3) & 3;
+    const int pix0 = (tid >> 5) * 8 + (tid & 7);
+    const int ldsA0 = q * plane_bytes + pix0 * 16;
+    const int cvalid = (p.Cin - q * VEC + KC - 1) / KC;
+    unsigned aoff[AR];
+#pragma unroll
+    for (int u = 0; u < AR; ++u) {
+        const int pix = pix0 + 64 * u;
+        const int ry = (int)__umulhi((unsigned)pix, p.pw_magic), rx = pix - ry * PW;
+        const int y = iy0 + ry, x = ix0 + rx;
+        const bool ok = pix < npix && (unsigned)y < (unsigned)p.Hin && (unsigned)x < (unsigned)p.Win;
+        aoff[u] = ok ? (unsigned)(((y * p.Win + x) * p.in_ld + p.in_coff + q * VEC) * (int)sizeof(T)) : OOB;
+    }
+    vec ra[AR];
+    auto issue = [&](int c) {
+        const bool qok = c < cvalid;
+#pragma unroll
+        for (int u = 0; u < AR; ++u)
+            if (pix0 + 64 * u < ((npix + 7) & ~7))
+                ra[u] = buf_load16<vec>(rsA, qok ? aoff[u] : OOB, (unsigned)(c * KC * (int)sizeof(T)));
+    };
+    // the 64 KB of weight fragments of a chunk are fetched inside commit() (short-lived registers, L2-resident data) instead of
+    // being carried across the MFMA loop: 16 pieces per thread would not fit beside the accumulators at 2 workgroups per CU
+    auto commit = [&](int c) {
+        const unsigned sB = (unsigned)((size_t)c * (NTB * TAPS * 1024));
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            vec rb[BR / 2];
+#pragma unroll
+            for (int u = 0; u < BR / 2; ++u) rb[u] = buf_load16<vec>(rsB, (unsigned)(tid + (h * (BR / 2) + u) * 256) * 16u, sB);
+            if (h == 0) {
+#pragma unroll
+                for (int u = 0; u < AR; ++u)
+                    if (pix0 + 64 * u < npix) *(vec*)(smA + ldsA0 + u * 1024) = ra[u];
+            }
+#pragma unroll
+            for (int u = 0; u < BR / 2; ++u) *(vec*)(smB + (tid + (h * (BR / 2) + u) * 256) * 16) = rb[u];
+        }
+    };
+
+    issue(0);
+    for (int c = 0; c < p.nchunks; ++c) {
+        commit(c);
+        __syncthreads();
+        if (c + 1 < p.nchunks) issue(c + 1);
+        {
+            constexpr int NSTEP = TAPS * MREP;
+            vec xq[3];
+            vec wq[2][NREP];
+            auto ldx = [&](int s_) -> vec {
+                const int tp = s_ / MREP, mm = s_ % MREP;
+                return *(const vec*)(smA + abase[mm] + ((tp >> 1) * PW + (tp & 1)) * 16);
+            };
+            auto ldw = [&](int tp, vec (&w)[NREP]) {
+#pragma unroll
+                for (int n = 0; n < NREP; ++n) w[n] = *(const vec*)(smB + ((wave * NREP + n) * TAPS + tp) * 1024 + lane * 16);
+            };
+            ldw(0, wq[0]);
+            xq[0] = ldx(0);
+            xq[1] = ldx(1);
+#pragma unroll
+            for (int s_ = 0; s_ < NSTEP; ++s_) {
+                const int tp = s_ / MREP, mm = s_ % MREP;
+                if (s_ + 2 < NSTEP) xq[(s_ + 2) % 3] = ldx(s_ + 2);
+                if (mm == 0 && tp + 1 < TAPS) ldw(tp + 1, wq[(tp + 1) % 2]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int n = 0; n < NREP; ++n) acc[mm][n] = mma(wq[tp % 2][n], xq[s_ % 3], acc[mm][n]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (c + 1 < p.nchunks) __syncthreads();
+    }
+    conv_stage2<T, NREP, NREP2, true>(p, acc, pvalid, opy, opx, b, lane);
+}
+
+template <typename T>
+static hipError_t launch_convfold_t(const ConvParams& p, dim3 grid, size_t lds, hipStream_t st) {
+#define VTI_FOLD(N2)                                                                                                   \
+    if (p.ntiles2 == N2) {                                                                                             \
+        auto k = convfold_kernel<T, N2>;                                                                               \
+        static bool done_dev[kMaxDevices] = {};                                                                        \
+        bool& done = done_dev[current_device_slot()];                                                                  \
+        if (!done) {                                                                                                   \
+            hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            if (e != hipSuccess) return e;                                                                             \
+            done = true;                                                                                               \
+        }                                                                                                              \
+        hipLaunchKernelGGL(k, grid, dim3(256), lds, st, p);                                                            \
+        return hipGetLastError();                                                                                      \
+    }
+    VTI_FOLD(1) VTI_FOLD(2) VTI_FOLD(4)
+#undef VTI_FOLD
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_convfold(int dtype, const ConvParams& p, size_t lds_bytes, hipStream_t st) {
+    dim3 grid((unsigned)(p.B * p.tiles_y * p.tiles_x));
+    if (grid.x == 0) return hipSuccess;
+    // host-side shape guards for the kernel's fixed staging arrays: 80 pixels per workgroup, <= 8 patch pieces per thread
+    if (p.TH * p.TW > MREP * 16 || ((p.TH + 2) * (p.TW + 2) + 7) / 8 * 32 > 256 * 8 || p.Cout != 256 || !p.out2 || !p.fold)
+        return hipErrorInvalidValue;
+    if (dtype == VTI_F16) return launch_convfold_t<half_t>(p, grid, lds_bytes, st);
+    return launch_convfold_t<float>(p, grid, lds_bytes, st);
+}
+
 // ---- stem conv (model.0): u8 HWC3 frame -> /255 -> 3x3 stride-2 conv, K = 27 padded to 32.
 // The (2TH+1) x (2TW+1) x 3-byte input patch is copied to LDS with aligned dword loads; an exact
 // 256-entry table gives T(v/255.0f) (what torch computes for `im.float()/255`, then .half()); every

@@ -243,9 +243,12 @@ template <typename V> __device__ __forceinline__ V buf_load16(__amdgpu_buffer_rs
 }
 
 // ---- fused 1x1 second stage on the register tile of a 3x3 conv (WN == 1).
-template <typename T, int NREP, int NREP2>
+// FOLD (convfold_kernel): opy/opx are coordinates on the 2 Hout x 2 Wout output grid and the stage-1 bias depends on the output
+// pixel's border class (p.bias = [3 x 3][16 NREP] floats, weights.cpp: pack_conv_fold).
+template <typename T, int NREP, int NREP2, bool FOLD = false>
 __device__ __forceinline__ void conv_stage2(const ConvParams& p, f32x4 (&acc)[MREP][NREP], const bool (&pvalid)[MREP],
                                             const int (&opy)[MREP], const int (&opx)[MREP], int b, int lane) {
+    const int OW = FOLD ? 2 * p.Wout : p.Wout;        // width of the grid the second stage stores on
     using vec = typename Tr<T>::vec;
     // ---- fused 1x1 second stage on the register tile (WN == 1: this wave holds every mid channel
     // of its 80 pixels).  silu(acc + bias) in fp16/fp32 IS the MFMA pixel operand of the next GEMM:
@@ -255,9 +258,19 @@ __device__ __forceinline__ void conv_stage2(const ConvParams& p, f32x4 (&acc)[MR
     constexpr int KT = sizeof(T) == 2 ? (NREP + 1) / 2 : NREP;
     const __amdgpu_buffer_rsrc_t rsW2 = __builtin_amdgcn_make_buffer_rsrc(
         (void*)p.w2, 0, (int)(KT * p.ntiles2 * 1024), 0x00020000);
-    f32x4 bias1[NREP];
+    f32x4 bias1[FOLD ? MREP : 1][NREP];
+    if constexpr (FOLD) {
 #pragma unroll
-    for (int n = 0; n < NREP; ++n) bias1[n] = *(const f32x4*)(p.bias + (lane >> 4) * 4 * NREP + 4 * n);
+        for (int m = 0; m < MREP; ++m) {
+            const int cy = opy[m] == 0 ? 0 : (opy[m] == 2 * p.Hout - 1 ? 2 : 1), cx = opx[m] == 0 ? 0 : (opx[m] == OW - 1 ? 2 : 1);
+            const float* bt = p.bias + (cy * 3 + cx) * (16 * NREP) + (lane >> 4) * 4 * NREP;
+#pragma unroll
+            for (int n = 0; n < NREP; ++n) bias1[m][n] = *(const f32x4*)(bt + 4 * n);
+        }
+    } else {
+#pragma unroll
+        for (int n = 0; n < NREP; ++n) bias1[0][n] = *(const f32x4*)(p.bias + (lane >> 4) * 4 * NREP + 4 * n);
+    }
     f32x4 acc2[MREP][NREP2];
 #pragma unroll
     for (int m = 0; m < MREP; ++m)
@@ -278,14 +291,14 @@ __device__ __forceinline__ void conv_stage2(const ConvParams& p, f32x4 (&acc)[MR
                     const int n1 = 2 * t2 + h;
                     f32x4 v = {0.f, 0.f, 0.f, 0.f};
                     if (n1 < NREP) {
-                        v = acc[m][n1 < NREP ? n1 : 0] + bias1[n1 < NREP ? n1 : 0];
+                        v = acc[m][n1 < NREP ? n1 : 0] + bias1[FOLD ? m : 0][n1 < NREP ? n1 : 0];
                         if (p.act) v = silu4<FAST>(v);
                     }
 #pragma unroll
                     for (int j = 0; j < 4; ++j) x[h * 4 + j] = (T)v[j];
                 }
             } else {
-                f32x4 v = acc[m][t2] + bias1[t2];
+                f32x4 v = acc[m][t2] + bias1[FOLD ? m : 0][t2];
                 if (p.act) v = silu4<FAST>(v);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) x[j] = v[j];
@@ -337,7 +350,7 @@ __device__ __forceinline__ void conv_stage2(const ConvParams& p, f32x4 (&acc)[MR
                 const float comp = g == 0 ? ((x1 + x2) / 2.0f) * p.dfl_stride : g == 1 ? ((y1 + y2) / 2.0f) * p.dfl_stride
                                  : g == 2 ? (x2 - x1) * p.dfl_stride : (y2 - y1) * p.dfl_stride;
                 if (pvalid[m])
-                    ((float*)p.out2)[((size_t)b * p.out2_bstride + (size_t)opy[m] * p.Wout + opx[m]) * p.out2_ld + p.out2_coff + g] = comp;
+                    ((float*)p.out2)[((size_t)b * p.out2_bstride + (size_t)opy[m] * OW + opx[m]) * p.out2_ld + p.out2_coff + g] = comp;
             }
             return;
         }
@@ -349,7 +362,7 @@ __device__ __forceinline__ void conv_stage2(const ConvParams& p, f32x4 (&acc)[MR
 #pragma unroll
             for (int m = 0; m < MREP; ++m) {
                 if (!pvalid[m]) continue;
-                half_t* op = (half_t*)p.out2 + ((size_t)b * p.out2_bstride + (size_t)opy[m] * p.Wout + opx[m]) * p.out2_ld + p.out2_coff + crun2;
+                half_t* op = (half_t*)p.out2 + ((size_t)b * p.out2_bstride + (size_t)opy[m] * OW + opx[m]) * p.out2_ld + p.out2_coff + crun2;
 #pragma unroll
                 for (int n = 0; n < NREP2; n += 2) {
                     if (crun2 + 4 * n >= p.Cout2) continue;
@@ -368,7 +381,7 @@ __device__ __forceinline__ void conv_stage2(const ConvParams& p, f32x4 (&acc)[MR
     for (int m = 0; m < MREP; ++m) {
         if (!pvalid[m]) continue;
         // out2_bstride = pixels per frame of the destination: Hout*Wout, or the anchor count when the towers write into pred
-        const size_t o0 = ((size_t)b * p.out2_bstride + (size_t)opy[m] * p.Wout + opx[m]) * p.out2_ld + p.out2_coff;
+        const size_t o0 = ((size_t)b * p.out2_bstride + (size_t)opy[m] * OW + opx[m]) * p.out2_ld + p.out2_coff;
 #pragma unroll
         for (int n = 0; n < NREP2; ++n) {
             const int cout0 = crun2 + cstep2 * n;

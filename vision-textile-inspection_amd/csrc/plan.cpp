@@ -429,6 +429,33 @@ std::string Plan::build(const vti_desc& d) {
         }
     }
 
+    // Fold "ConvTranspose2d(2,2) -> 3x3 conv (+ fused 1x1)" (proto.upsample -> proto.cv2 -> proto.cv3) into ONE kernel of four
+    // 2x2 convs on the low-resolution map (weights.cpp: pack_conv_fold): the deconv's 4x larger output tensor is neither
+    // written nor read and the pair costs 2.25x fewer MACs.
+    {
+        const char* nf = getenv("VTI_NO_FOLD");
+        for (size_t i = 0; !(nf && nf[0] == '1') && i + 1 < ops.size(); ++i) {
+            const Op& u = ops[i];
+            Op& v = ops[i + 1];
+            if (u.kind != OP_CONV || v.kind != OP_CONV || u.lane != v.lane || v.fused < 0 || u.fused >= 0) continue;
+            const ConvRow& ru = convs[u.conv];
+            const ConvRow& rv = convs[v.conv];
+            if (!(ru.kind == 2 && ru.k == 2 && ru.s == 2 && rv.kind == 0 && rv.k == 3 && rv.s == 1) || u.has_res || v.has_res) continue;
+            if (v.in.buf != u.out.buf || v.in.coff != u.out.coff || v.in.C != u.out.C || u.out.C != bufs[u.out.buf].C) continue;
+            if (u.in.coff != 0 || u.in.C != bufs[u.in.buf].C) continue;
+            if (!convfold_supported(ru.c1, ru.c2, rv.c2, (convs[v.fused].c2 + 15) / 16)) continue;
+            bool other_reader = false;
+            for (size_t j = 0; j < ops.size(); ++j)
+                if (j != i + 1 && (ops[j].kind == OP_CONV || ops[j].kind == OP_UP2 || ops[j].kind == OP_POOL) &&
+                    (ops[j].in.buf == u.out.buf || (ops[j].has_res && ops[j].res.buf == u.out.buf))) other_reader = true;
+            if (other_reader) continue;
+            v.fold = u.conv;
+            v.in = u.in;
+            conv_out[u.conv].buf = -1;          // the upsampled tensor does not exist any more
+            ops.erase(ops.begin() + i);
+        }
+    }
+
     // stem + layer 1 in one kernel (n-scale channel counts: 3 -> 16 -> 32): the 320x320x16 tensor stays in LDS
     {
         const char* nsf = getenv("VTI_NO_STEM_FUSE");
@@ -530,7 +557,16 @@ std::string Plan::build(const vti_desc& d) {
         if (const char* pl = getenv("VTI_PK_LIMIT_BYTES")) pk_limit = (size_t)atoll(pl);
         const bool pk_ok = bufs[op.in.buf].bytes < pk_limit && bufs[op.out.buf].bytes < pk_limit &&
                            (!op.has_res || bufs[op.res.buf].bytes < pk_limit);
-        if (op.fused_l1 >= 0) choose_conv_cfg(d.dtype, r, true, d.max_batch, op.cfg, 0, 0, 1, 1);   // one 16-channel n-tile: stem_l1_kernel's weight indexing
+        if (op.fold >= 0) {         // convfold_kernel: 4 x 20 low-resolution pixels per workgroup, wave = output phase, 4 n-tiles each
+            const ConvRow& ru = convs[op.fold];
+            macs += ru.macs(); fused_params += ru.fused_params();
+            const int KC = d.dtype == VTI_F16 ? 32 : 16;
+            op.cfg = ConvCfg();
+            op.cfg.TH = 4; op.cfg.TW = 20; op.cfg.WN = 4; op.cfg.NREP = r.c2 / 16;
+            op.cfg.nchunks = (ru.c1 + KC - 1) / KC; op.cfg.gemm_n = 4 * r.c2; op.cfg.ntiles_n = 4 * (r.c2 / 16);
+            op.cfg.lds = convfold_lds_bytes(op.cfg.TH, op.cfg.TW);
+        }
+        else if (op.fused_l1 >= 0) choose_conv_cfg(d.dtype, r, true, d.max_batch, op.cfg, 0, 0, 1, 1);   // one 16-channel n-tile: stem_l1_kernel's weight indexing
         else if (op.fused >= 0) {   // whole Cout in one wave; the per-tile kernel (2 workgroups per CU) hides the long fused epilogue better
             const char* pf = getenv("VTI_PK_FUSED");
             choose_conv_cfg(d.dtype, r, false, d.max_batch, op.cfg, 0, 0, 1, r.c2 / 16, pk_ok && pf && pf[0] == '1');
@@ -540,8 +576,8 @@ std::string Plan::build(const vti_desc& d) {
         op.nat2 = (op.fused >= 0 && op.fused_l1 < 0 && (op.pred_mode || op.out2_f32)) ? 1 : 0;
         op.cfg.wpk_off = woff;
         op.cfg.bias_off = boff;
-        woff += packed_conv_bytes(r, op.kind == OP_CONV0, op.cfg);
-        boff += (size_t)op.cfg.ntiles_n * 16;
+        if (op.fold >= 0) { woff += packed_fold_bytes(op.cfg); boff += (size_t)9 * r.c2; }      // bias: [3 x 3 border classes][Cout]
+        else { woff += packed_conv_bytes(r, op.kind == OP_CONV0, op.cfg); boff += (size_t)op.cfg.ntiles_n * 16; }
         if (op.fused_l1 >= 0) {
             const ConvRow& r1 = convs[op.fused_l1];
             macs += r1.macs(); fused_params += r1.fused_params();

@@ -117,6 +117,8 @@ int32_t vti_conv_at(const vti_ctx* c, int32_t i, vti_conv_info* o) {
         if (op.conv == i) {
             o->tile_h = op.cfg.TH; o->tile_w = op.cfg.TW; o->waves_n = op.cfg.WN; o->nrep = op.cfg.NREP;
             o->lds_bytes = (int32_t)op.cfg.lds; o->persistent = op.cfg.pk;   // 1: conv3_pk, 2: conv1_pk
+        } else if (op.fold == i) {      // ConvTranspose folded into the following 3x3 (convfold_kernel): never materialised
+            o->tile_h = op.cfg.TH; o->tile_w = op.cfg.TW; o->waves_n = 4; o->nrep = op.cfg.NREP; o->lds_bytes = 0;   // `fused` stays 0: that flag means "runs inside the PREVIOUS row's kernel"
         } else if (op.fused_l1 == i) {  // layer 1 inside the stem's kernel (stem_l1_kernel: 16 x 20 output tiles, 2 n-tiles)
             stem_l1_tile(&o->tile_h, &o->tile_w); o->waves_n = 1; o->nrep = 2; o->lds_bytes = 0; o->fused = 1;
         } else if (op.fused == i) {     // runs inside its producer's kernel, on that kernel's geometry
@@ -303,7 +305,7 @@ int32_t vti_forward(vti_ctx* c, const uint8_t* input, int32_t B, int32_t swap_rb
             const bool cv = op.kind == OP_CONV || op.kind == OP_CONV0;
             fprintf(stderr, "[op %2d] lane %d %s%s%s\n", i++, op.lane,
                     cv ? P.convs[op.conv].name.c_str() : op.kind == OP_POOL ? "sppf_pool" : op.kind == OP_UP2 ? "upsample2x" : "decode",
-                    cv && op.fused_l1 >= 0 ? (" + " + P.convs[op.fused_l1].name).c_str() : "",
+                    cv && op.fused_l1 >= 0 ? (" + " + P.convs[op.fused_l1].name).c_str() : cv && op.fold >= 0 ? (" (folded: " + P.convs[op.fold].name + ")").c_str() : "",
                     cv && op.fused >= 0 ? (" + " + P.convs[op.fused].name).c_str() : "");
         }
     }
@@ -370,6 +372,27 @@ int32_t vti_forward(vti_ctx* c, const uint8_t* input, int32_t B, int32_t swap_rb
                 }
 #endif
                 VTI_HIP(c, launch_stem_l1(dt, q, st), "stem + layer 1");
+                break;
+            }
+            if (op.fold >= 0) {         // ConvTranspose2d(2,2) + 3x3 + fused 1x1 as four 2x2 convs on the low-resolution map
+                const ConvRow& ru = P.convs[op.fold];
+                const Buf& o2 = P.bufs[op.out2.buf];
+                ConvParams q;
+                memset(&q, 0, sizeof q);
+                q.in = buf_ptr(c, op.in.buf, input, proto); q.B = B; q.Hin = ru.h_in; q.Win = ru.w_in; q.Hout = ru.h_in; q.Wout = ru.w_in;
+                q.Cin = ru.c1; q.in_ld = ib.C; q.in_coff = op.in.coff; q.Cout = g.gemm_n; q.act = 1; q.fold = 1;
+                q.TH = g.TH; q.TW = g.TW; q.tiles_y = (q.Hout + g.TH - 1) / g.TH; q.tiles_x = (q.Wout + g.TW - 1) / g.TW; q.WN = 4;
+                q.nchunks = g.nchunks; q.ntiles_n = g.ntiles_n;
+                q.pw_magic = (unsigned)((0x100000000ull + (unsigned)(g.TW + 2) - 1) / (unsigned)(g.TW + 2));
+                q.tw_magic = (unsigned)((0x100000000ull + (unsigned)g.TW - 1) / (unsigned)g.TW);
+                q.wpk = (const char*)c->d_wpk + g.wpk_off; q.bias = c->d_bias + g.bias_off; q.wpk_bytes = (unsigned)packed_fold_bytes(g);
+                q.w2 = (const char*)c->d_wpk + g.wpk_off2; q.bias2 = c->d_bias + g.bias_off2;
+                q.out2 = buf_ptr(c, op.out2.buf, input, proto);
+                q.Cout2 = g.gemm_n2; q.ntiles2 = g.ntiles2; q.out2_ld = o2.C; q.out2_coff = op.out2.coff;
+                q.act2 = P.convs[op.fused].kind == 0; q.out2_f32 = op.out2_f32 ? 1 : 0;
+                q.scalar_store2 = (g.gemm_n2 % 4 || o2.C % 4 || op.out2.coff % 4) ? 1 : 0;
+                q.out2_bstride = 4 * q.Hout * q.Wout;
+                VTI_HIP(c, launch_convfold(dt, q, g.lds, st), r.name.c_str());
                 break;
             }
             ConvParams p;

@@ -70,6 +70,7 @@ struct Op {
     bool has_res = false;
     bool out_f32 = false;
     int fused = -1;      // conv index of a 1x1 conv fused into this op's epilogue (its own op is dropped)
+    int fold = -1;       // conv index of a ConvTranspose2d(2,2) FOLDED into this 3x3 conv (convfold_kernel): `in` is then the deconv's input
     int fused_l1 = -1;   // OP_CONV0 only: conv index of layer 1 computed by the same kernel (stem_l1_kernel); out/out2 = layer 1's view
     int pred_mode = 0, pred_cbase = 0, pred_a0 = 0;   // fused stage writes into pred instead of a head buffer (1 raw, 2 sigmoid, 3 DFL boxes)
     int dfl_stride = 0;      // pred_mode 3: the level's stride (box tower: DFL expectation + dist2bbox in the epilogue)
@@ -123,6 +124,7 @@ struct ConvParams {
     unsigned in_bytes, out_bytes, res_bytes;
     // conv1_pk: channels [0, up_C) come from in2 [B, Hout/2, Wout/2, in2_ld] at (y >> 1, x >> 1): the neck's Upsample + Concat folded into the loads
     const void* in2; int in2_ld, in2_coff, up_C; unsigned in2_bytes;
+    int fold;                            // convfold_kernel: stage-2 output grid is 2 Hout x 2 Wout, stage-1 bias = p.bias[border class][64]
     const void* w0; const float* bias0;  // stem_l1_kernel: the stem's packed weights / bias (wpk/bias = layer 1, w2/bias2 = the fused 1x1 third conv)
     unsigned long long* stamps;          // diagnostic build only (VTI_STAMPS): 16 s_memtime slots per workgroup
 };
@@ -137,6 +139,13 @@ bool conv_cfg_fits(int ks, int stride, int mode, int TH, int TW, int WN, int NRE
 hipError_t launch_stem_l1(int dtype, const ConvParams& p, hipStream_t st);
 size_t stem_l1_lds_bytes(int dtype);
 void stem_l1_tile(int* th, int* tw);
+// ConvTranspose2d(C,C,2,2) folded into the following 3x3 conv (+ its fused 1x1): four 2x2 convs on the low-resolution map
+hipError_t launch_convfold(int dtype, const ConvParams& p, size_t lds_bytes, hipStream_t st);
+size_t convfold_lds_bytes(int TH, int TW);
+bool convfold_supported(int c_in, int c_mid, int c_out, int ntiles2);
+void pack_conv_fold(int dtype, const ConvRow& rU, const ConvRow& rV, const ConvCfg& c, const float* wU, const float* bU,
+                    const float* wV, const float* bV, uint8_t* dst_w, float* dst_b);
+size_t packed_fold_bytes(const ConvCfg& c);
 void pack_conv_l1pairs(int dtype, const ConvRow& r1, const float* w, const float* b, uint8_t* dst_w, float* dst_b);
 size_t packed_l1pairs_bytes(int dtype);
 // conv_pk.hip: persistent 3x3/s1 kernel

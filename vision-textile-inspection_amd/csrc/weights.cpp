@@ -105,6 +105,75 @@ void pack_conv_stage2(int dtype, const ConvRow& r2, int nrep1, const float* w, c
     for (int n = 0; n < nt2 * 16; ++n) bd[n] = n < r2.c2 ? b[n] : 0.f;
 }
 
+// ConvTranspose2d(C, M, 2, 2, bias) [rU, IOHW] folded into the 3x3 conv that follows it [rV: M -> O, pad 1]
+// (proto.upsample -> proto.cv2).  With U[Y][X] = bU + WU[:, :, Y&1, X&1]^T P[Y>>1][X>>1] and zero padding of U,
+//   V[2y+py][2x+px] = bV' + sum_{a,b in {0,1}} Weff[py][px][a][b] P[y-1+py+a][x-1+px+b]
+//   Weff[py][px][a][b][o][c] = sum over the 3x3 taps (dy,dx) whose source row/column falls on window row a / column b of
+//                              sum_m WV[o][m][dy][dx] WU[c][m][r][q],   (r, q) = parity of (py+dy, px+dx),
+// i.e. four 2x2 convolutions on the LOW-resolution map (K = 4 C instead of 9 M at 4x the pixels: 2.25x fewer MACs, and the
+// deconv's output tensor never exists).  P outside the map reads as zero; what remains of the padding is the deconv BIAS of
+// taps that fall outside U, which depends on the output pixel's border class (first / interior / last row x column):
+//   bias[cy][cx][o] = bV[o] + sum_{dy valid for cy, dx valid for cx} sum_m WV[o][m][dy][dx] bU[m].
+// Exact in real arithmetic; in floating point the composed weights are rounded once (instead of rounding U), which stays
+// inside the per-layer tolerance of the parity tests (tests/test_gpu_forward.py).
+// Packed as a conv with gemm N = 4 phases x O (phase-major), 4 taps (a, b), rows permuted per phase group.
+size_t packed_fold_bytes(const ConvCfg& c) { return (size_t)c.nchunks * c.ntiles_n * 4 * 1024; }
+
+void pack_conv_fold(int dtype, const ConvRow& rU, const ConvRow& rV, const ConvCfg& c, const float* wU, const float* bU,
+                    const float* wV, const float* bV, uint8_t* dst_w, float* dst_b) {
+    const int C = rU.c1, M = rU.c2, O = rV.c2;
+    // tap (dy in -1..1) of output parity py -> (window row a, deconv parity r): source row 2y+py+dy = 2 (y-1+py+a) + r
+    auto split = [](int py, int dy, int& a, int& r) {
+        const int t = py + dy;                     // -1 .. 2
+        const int lo = t >= 0 ? t / 2 : -1;         // floor(t / 2)
+        r = t - 2 * lo;
+        a = lo + 1 - py;                            // window row 0 is low-res row y - 1 + py
+    };
+    std::vector<float> weff((size_t)4 * O * C * 4, 0.f);         // [(phase, o)][c][a][b]  (OIHW with k = 2)
+    std::vector<double> acc((size_t)O * C);
+    for (int py = 0; py < 2; ++py)
+        for (int px = 0; px < 2; ++px)
+            for (int a = 0; a < 2; ++a)
+                for (int b = 0; b < 2; ++b) {
+                    std::fill(acc.begin(), acc.end(), 0.0);
+                    for (int dy = -1; dy <= 1; ++dy)
+                        for (int dx = -1; dx <= 1; ++dx) {
+                            int aa, r, bb, q;
+                            split(py, dy, aa, r); split(px, dx, bb, q);
+                            if (aa != a || bb != b) continue;
+                            for (int o = 0; o < O; ++o)
+                                for (int m = 0; m < M; ++m) {
+                                    const double wv = wV[(((size_t)o * M + m) * 3 + (dy + 1)) * 3 + (dx + 1)];
+                                    for (int ci = 0; ci < C; ++ci)
+                                        acc[(size_t)o * C + ci] += wv * (double)wU[(((size_t)ci * M + m) * 2 + r) * 2 + q];
+                                }
+                        }
+                    const int ph = py * 2 + px;
+                    for (int o = 0; o < O; ++o)
+                        for (int ci = 0; ci < C; ++ci)
+                            weff[((((size_t)ph * O + o) * C + ci) * 2 + a) * 2 + b] = (float)acc[(size_t)o * C + ci];
+                }
+    ConvRow syn;
+    syn.name = "fold"; syn.c1 = C; syn.c2 = 4 * O; syn.k = 2; syn.s = 1; syn.kind = 0;
+    syn.h_in = syn.w_in = syn.h_out = syn.w_out = 0;
+    ConvCfg sc = c;
+    sc.gemm_n = 4 * O;
+    std::vector<float> zero_b((size_t)4 * O, 0.f), bias_sink((size_t)c.ntiles_n * 16);
+    pack_conv(dtype, syn, false, sc, weff.data(), zero_b.data(), dst_w, bias_sink.data());
+    // bias table [cy][cx][O]: class 0 = first row/column (tap -1 outside), 1 = interior, 2 = last (tap +1 outside)
+    for (int cy = 0; cy < 3; ++cy)
+        for (int cx = 0; cx < 3; ++cx)
+            for (int o = 0; o < O; ++o) {
+                double v = bV[o];
+                for (int dy = -1; dy <= 1; ++dy)
+                    for (int dx = -1; dx <= 1; ++dx) {
+                        if ((cy == 0 && dy < 0) || (cy == 2 && dy > 0) || (cx == 0 && dx < 0) || (cx == 2 && dx > 0)) continue;
+                        for (int m = 0; m < M; ++m) v += (double)wV[(((size_t)o * M + m) * 3 + (dy + 1)) * 3 + (dx + 1)] * (double)bU[m];
+                    }
+                dst_b[((size_t)cy * 3 + cx) * O + o] = (float)v;
+            }
+}
+
 // Layer 1 (16 -> 32, k3 s2) inside stem_l1_kernel: K = 9 taps x 16 channels walked in MFMA steps that pair taps.
 // fp16: step s, lane group g -> tap 2s + (g >> 1), channels 8 (g & 1) + j (j < 8); the 10th half-step is zero.
 // fp32: step s = tap s, channels 4 g + j (j < 4).  Layout [step][ntile 0..1][lane][VEC]; rows permuted as for NREP = 2.
@@ -152,6 +221,11 @@ std::string pack_weights(const Plan& plan, const void* blob, size_t nbytes, std:
             if (op.fused_l1 >= 0) l1_host[op.fused_l1] = &op;
         }
 
+    std::vector<const Op*> fold_host(plan.convs.size(), nullptr);      // deconv index -> the 3x3 op it is folded into
+    for (const Op& op : plan.ops)
+        if ((op.kind == OP_CONV) && op.fold >= 0) fold_host[op.fold] = &op;
+    std::vector<float> fold_w, fold_b;                                  // the folded deconv's tensors, kept until its 3x3 arrives
+
     size_t off = sizeof(Hdr);
     for (size_t i = 0; i < plan.convs.size(); ++i) {
         const ConvRow& r = plan.convs[i];
@@ -170,6 +244,13 @@ std::string pack_weights(const Plan& plan, const void* blob, size_t nbytes, std:
         memcpy(w.data(), p + off, 4 * nw); off += 4 * nw;
         memcpy(b.data(), p + off, 4 * (size_t)r.c2); off += 4 * (size_t)r.c2;
 
+        if (fold_host[i]) { fold_w = w; fold_b = b; continue; }          // packed together with the 3x3 that follows
+        if (op_of[i] && op_of[i]->fold >= 0) {
+            const Op& op = *op_of[i];
+            pack_conv_fold(plan.desc.dtype, plan.convs[op.fold], r, op.cfg, fold_w.data(), fold_b.data(), w.data(), b.data(),
+                           wpk.data() + op.cfg.wpk_off, bias.data() + op.cfg.bias_off);
+            continue;
+        }
         if (l1_host[i]) {      // layer 1 computed inside the stem's kernel
             const ConvCfg& hc = l1_host[i]->cfg;
             pack_conv_l1pairs(plan.desc.dtype, r, w.data(), b.data(), wpk.data() + hc.wpk_off2, bias.data() + hc.bias_off2);
