@@ -243,11 +243,39 @@ template <typename V> __device__ __forceinline__ V buf_load16(__amdgpu_buffer_rs
 }
 
 // ---- fused 1x1 second stage on the register tile of a 3x3 conv (WN == 1).
+// Operands of the fused stage that do not depend on the tile: a persistent kernel loads them once (stage2_preload) instead of once
+// per tile, where one compute wave per SIMD would wait for each of them in the open.
+template <typename T, int NREP, int NREP2> struct Stage2Regs {
+    using vec = typename Tr<T>::vec;
+    static constexpr int KT = sizeof(T) == 2 ? (NREP + 1) / 2 : NREP;
+    vec w2[KT][NREP2];
+    f32x4 bias1[NREP];          // FOLD: the interior border class
+    f32x4 bias2[NREP2];
+};
+
 // FOLD (convfold_kernel): opy/opx are coordinates on the 2 Hout x 2 Wout output grid and the stage-1 bias depends on the output
 // pixel's border class (p.bias = [3 x 3][16 NREP] floats, weights.cpp: pack_conv_fold).
-template <typename T, int NREP, int NREP2, bool FOLD = false>
+template <typename T, int NREP, int NREP2>
+__device__ __forceinline__ void stage2_preload(const ConvParams& p, int lane, bool fold, Stage2Regs<T, NREP, NREP2>& r) {
+    using vec = typename Tr<T>::vec;
+    const __amdgpu_buffer_rsrc_t rsW2 = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.w2, 0, (int)(Stage2Regs<T, NREP, NREP2>::KT * p.ntiles2 * 1024), 0x00020000);
+#pragma unroll
+    for (int t2 = 0; t2 < Stage2Regs<T, NREP, NREP2>::KT; ++t2)
+#pragma unroll
+        for (int n = 0; n < NREP2; ++n) r.w2[t2][n] = buf_load16<vec>(rsW2, (unsigned)(((t2 * p.ntiles2 + n) * 64 + lane) * 16), 0u);
+    const float* b1 = p.bias + (fold ? 4 * (16 * NREP) : 0) + (lane >> 4) * 4 * NREP;      // fold: class (1, 1) = interior
+#pragma unroll
+    for (int n = 0; n < NREP; ++n) r.bias1[n] = *(const f32x4*)(b1 + 4 * n);
+    const int crun2 = p.nat2 ? (lane >> 4) * 4 : (lane >> 4) * 4 * NREP2, cstep2 = p.nat2 ? 16 : 4;
+#pragma unroll
+    for (int n = 0; n < NREP2; ++n) r.bias2[n] = *(const f32x4*)(p.bias2 + crun2 + cstep2 * n);
+}
+
+template <typename T, int NREP, int NREP2, bool FOLD = false, bool PRE = false>
 __device__ __forceinline__ void conv_stage2(const ConvParams& p, f32x4 (&acc)[MREP][NREP], const bool (&pvalid)[MREP],
-                                            const int (&opy)[MREP], const int (&opx)[MREP], int b, int lane) {
+                                            const int (&opy)[MREP], const int (&opx)[MREP], int b, int lane,
+                                            const Stage2Regs<T, NREP, NREP2>* pre = nullptr, bool interior = false) {
     const int OW = FOLD ? 2 * p.Wout : p.Wout;        // width of the grid the second stage stores on
     using vec = typename Tr<T>::vec;
     // ---- fused 1x1 second stage on the register tile (WN == 1: this wave holds every mid channel
@@ -259,7 +287,12 @@ __device__ __forceinline__ void conv_stage2(const ConvParams& p, f32x4 (&acc)[MR
     const __amdgpu_buffer_rsrc_t rsW2 = __builtin_amdgcn_make_buffer_rsrc(
         (void*)p.w2, 0, (int)(KT * p.ntiles2 * 1024), 0x00020000);
     f32x4 bias1[FOLD ? MREP : 1][NREP];
-    if constexpr (FOLD) {
+    if (PRE && (!FOLD || interior)) {               // (wave-uniform) every pixel of the tile takes the preloaded vector
+#pragma unroll
+        for (int m = 0; m < (FOLD ? MREP : 1); ++m)
+#pragma unroll
+            for (int n = 0; n < NREP; ++n) bias1[m][n] = pre->bias1[n];
+    } else if constexpr (FOLD) {
 #pragma unroll
         for (int m = 0; m < MREP; ++m) {
             const int cy = opy[m] == 0 ? 0 : (opy[m] == 2 * p.Hout - 1 ? 2 : 1), cx = opx[m] == 0 ? 0 : (opx[m] == OW - 1 ? 2 : 1);
@@ -280,8 +313,10 @@ __device__ __forceinline__ void conv_stage2(const ConvParams& p, f32x4 (&acc)[MR
     for (int t2 = 0; t2 < KT; ++t2) {
         vec w2[NREP2];
 #pragma unroll
-        for (int n = 0; n < NREP2; ++n)
-            w2[n] = buf_load16<vec>(rsW2, (unsigned)(((t2 * p.ntiles2 + n) * 64 + lane) * 16), 0u);
+        for (int n = 0; n < NREP2; ++n) {
+            if constexpr (PRE) w2[n] = pre->w2[t2][n];
+            else w2[n] = buf_load16<vec>(rsW2, (unsigned)(((t2 * p.ntiles2 + n) * 64 + lane) * 16), 0u);
+        }
 #pragma unroll
         for (int m = 0; m < MREP; ++m) {
             vec x;
@@ -316,7 +351,10 @@ __device__ __forceinline__ void conv_stage2(const ConvParams& p, f32x4 (&acc)[MR
     const int crun2 = p.nat2 ? (lane >> 4) * 4 : (lane >> 4) * 4 * NREP2;
     const int cstep2 = p.nat2 ? 16 : 4;
 #pragma unroll
-    for (int n = 0; n < NREP2; ++n) bias2[n] = *(const f32x4*)(p.bias2 + crun2 + cstep2 * n);
+    for (int n = 0; n < NREP2; ++n) {
+        if constexpr (PRE) bias2[n] = pre->bias2[n];
+        else bias2[n] = *(const f32x4*)(p.bias2 + crun2 + cstep2 * n);
+    }
     if constexpr (NREP2 == 4) {
         if (p.act2 == 3) {
             // ---- box tower: DFL + dist2bbox here.  Natural channel order: tile n is side n (l,t,r,b) and lane

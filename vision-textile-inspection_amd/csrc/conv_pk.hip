@@ -24,6 +24,8 @@
 //    k-group, ds_read_b128) conflict-free for every tap: the row pitch is a multiple of 8 slots, so bit 2 of a
 //    slot index only depends on the tap's dx, and each lane keeps three precomputed addresses (dx = 0,1,2) with
 //    dy as an immediate offset.
+#include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 
 #include "conv_dev.h"
@@ -35,9 +37,25 @@ constexpr int PK_TW = 20;         // tile width (pixels)
 constexpr int PK_ROWS = 4;        // tile rows per M-wave: 4 x 20 = 80 pixels = MREP m-tiles
 constexpr int PK_MAXD = 9;        // patch DMA instructions per wave and step (host checks)
 
-size_t conv_pk_lds_bytes(int TH, int WN, int NREP, int nchunks) {
+// `depth` patch stages (2..4): the loaders run depth - 1 steps ahead.  Weights: K <= 2 chunks stay resident (1 or 2 buffers);
+// more chunks travel with the patches, one buffer per stage.
+size_t conv_pk_lds_bytes(int TH, int WN, int NREP, int nchunks, int depth) {
     const size_t stage = (size_t)(TH + 2) * PK_PWP * 64;
-    return 2 * stage + (size_t)(nchunks > 1 ? 2 : 1) * WN * NREP * 9 * 1024 + (size_t)WN * NREP * 16 * 4;
+    const int nwbuf = nchunks > 2 ? depth : (nchunks > 1 ? 2 : 1);
+    return depth * stage + (size_t)nwbuf * WN * NREP * 9 * 1024 + (size_t)WN * NREP * 16 * 4;
+}
+size_t conv_pk_lds_bytes(int TH, int WN, int NREP, int nchunks) { return conv_pk_lds_bytes(TH, WN, NREP, nchunks, 2); }
+
+// deepest ring (<= 4) that fits the 160 KiB of LDS and the counted-wait range; 0 = the geometry does not fit at all
+int conv_pk_depth(int TH, int WN, int NREP, int nchunks) {
+    if (!conv_pk_fits(TH, WN, NREP, nchunks)) return 0;
+    const char* cap = getenv("VTI_PK_DEPTH");
+    const int maxd = cap ? std::max(2, std::min(4, atoi(cap))) : 4;
+    const int ncomp = (TH / PK_ROWS) * WN;
+    const int per_step = ((TH + 2) * PK_PWP / 16 + ncomp - 1) / ncomp + (nchunks > 2 ? (WN * NREP * 9 + ncomp - 1) / ncomp : 0);
+    int d = 2;
+    while (d < maxd && conv_pk_lds_bytes(TH, WN, NREP, nchunks, d + 1) <= 160 * 1024 && per_step * (d - 1) <= 63) ++d;
+    return d;
 }
 
 bool conv_pk_fits(int TH, int WN, int NREP, int nchunks) {
@@ -57,12 +75,19 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, unsigned voff, u
 }
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "i"(N) : "memory"); }
+// counted wait with a run-time count: waits until at most min(n, N) of the wave's youngest vector-memory operations are pending
+template <int N> struct WaitVm { static __device__ __forceinline__ void go(int n) { if (n >= N) wait_vm<N>(); else WaitVm<N - 1>::go(n); } };
+template <> struct WaitVm<0> { static __device__ __forceinline__ void go(int) { wait_vm<0>(); } };
 
-template <typename T, int NREP, int WN, int NREP2 = 0>
+// FOLD: the ConvTranspose2d(2,2) -> 3x3 fold of conv.hip's convfold_kernel on this schedule: TH = 4, WN = 4 -- compute wave wn is
+// output phase (py, px) = (wn >> 1, wn & 1) and runs the 2x2 window that starts at patch (py, px) over the SAME 4 x 20 low-resolution
+// pixels as its three siblings (4 taps instead of 9; both K chunks of the 128 KB of composed weights stay in LDS for the whole
+// launch, where the per-tile kernel re-stages 64 KB per chunk and tile); its epilogue is the fused 1x1 stage on the 2x grid.
+template <typename T, int NREP, int WN, int NREP2 = 0, bool FOLD = false>
 __global__ __launch_bounds__(512) void conv3_pk(const ConvParams p) {
     using vec = typename Tr<T>::vec;
     constexpr int VEC = Tr<T>::VEC, KC = Tr<T>::KC, ES = (int)sizeof(T);
-    constexpr int TAPS = 9, NTB = WN * NREP;
+    constexpr int TAPS = FOLD ? 4 : 9, NTB = WN * NREP;
     constexpr int WCHUNK = NTB * TAPS * 1024;
     constexpr unsigned OOB = 0x80000000u;
     constexpr bool FAST = sizeof(T) == 2;
@@ -70,16 +95,18 @@ __global__ __launch_bounds__(512) void conv3_pk(const ConvParams p) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    static_assert(!FOLD || (WN == 4 && NREP2 > 0), "fold: one compute wave per output phase, fused 1x1 epilogue");
     const int ncomp = (p.TH / PK_ROWS) * WN;                // compute waves; the other blockDim/64 - ncomp waves load
     const int nld = (int)(blockDim.x >> 6) - ncomp;
     const int PH = p.TH + 2;
     const int stage_bytes = PH * PK_PWP * 64;
     const int ndma = PH * PK_PWP / 16;
-    const int wbuf_off = 2 * stage_bytes;
-    const int bias_off = wbuf_off + (p.nchunks > 1 ? 2 : 1) * WCHUNK;
+    const int D = p.pk_depth;                               // patch stages (ring depth)
+    const bool stream_w = p.nchunks > 2;
+    const int wbuf_off = D * stage_bytes;
+    const int bias_off = wbuf_off + (stream_w ? D : (p.nchunks > 1 ? 2 : 1)) * WCHUNK;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
     const int nt0 = blockIdx.y * NTB;
-    const bool stream_w = p.nchunks > 2;
 
     // bias of this workgroup's channels -> LDS (read back as 16-B pieces in the epilogue)
     for (int i = tid; i < NTB * 16; i += (int)blockDim.x) ((float*)(smem + bias_off))[i] = p.bias[nt0 * 16 + i];
@@ -101,11 +128,15 @@ __global__ __launch_bounds__(512) void conv3_pk(const ConvParams p) {
         const int ty = r % p.tiles_y;
         b = r / p.tiles_y; oy0 = ty * p.TH; ox0 = tx * PK_TW;
     };
+    const int nsteps = ((tend - t + tstride - 1) / tstride) * p.nchunks;
 
     if (wave >= ncomp) {
         // =================== loader waves: every LDS-DMA of the workgroup ===================
-        // Step s = (tile, chunk) pair.  DMA(s+1) is issued right after barrier(s) -- the compute waves finished
-        // reading that stage (step s-1) before they arrived at barrier(s) -- and waited for before barrier(s+1).
+        // Step s = (tile, chunk) pair, stage s % D.  The loaders run D - 1 steps ahead: DMA(s + D - 1) is issued right after
+        // barrier(s) -- the compute waves finished reading that stage (step s - 1) before they arrived there -- and before
+        // barrier(s) they wait with a COUNTED vmcnt for everything up to DMA(s) while the younger steps stay in flight
+        // (every loader wave issues the same number of DMA instructions in every step).  With steps of ~1.3 k MFMA cycles
+        // and ~2-4 k cycles of loaded memory latency a single step of look-ahead leaves the compute waves waiting at every barrier.
         const int lw = wave - ncomp;
         // piece i = lw + u * nld fills slots 16i .. 16i+15; lane l -> slot 16i + (l >> 2), 16-B position l & 3,
         // which holds channel piece q (source-side swizzle)
@@ -144,34 +175,39 @@ __global__ __launch_bounds__(512) void conv3_pk(const ConvParams p) {
             const unsigned dst = lds0 + wbuf_off + wb * WCHUNK;
             for (int f = lw; f < NTB * TAPS; f += nld) dma16(rsB, (unsigned)lane * 16u, src + f * 1024, dst + f * 1024);
         };
+        if (!stream_w) {                                    // resident weights first: the oldest operations, covered by every counted wait
+            issue_weights(0, 0);
+            if (p.nchunks == 2) issue_weights(1, 1);
+        }
+        int per_step = 0;
+#pragma unroll
+        for (int u = 0; u < PK_MAXD; ++u) per_step += (lw + u * nld < ndma) ? 1 : 0;
+        if (stream_w && lw < NTB * TAPS) per_step += (NTB * TAPS - lw + nld - 1) / nld;
+        int it = t, ic = 0;                                 // (tile, chunk) of the next step to issue
         setup_voff(t);
-        issue_patch(0, 0);
-        issue_weights(0, 0);
-        if (p.nchunks == 2) issue_weights(1, 1);
-        int step = 0;
-        while (true) {
-            const int tn = t + tstride;
-            for (int c = 0; c < p.nchunks; ++c, ++step) {
-                wait_vm<0>();
-                __builtin_amdgcn_s_barrier();
-                const int nxt = (step + 1) & 1;
-                if (c + 1 < p.nchunks) {
-                    issue_patch(c + 1, nxt);
-                    if (stream_w) issue_weights(c + 1, nxt);
-                } else if (tn < tend) {
-                    setup_voff(tn);
-                    issue_patch(0, nxt);
-                    if (stream_w) issue_weights(0, nxt);
-                }
+        auto issue_next = [&](int s) {
+            const int stage = s % D;
+            issue_patch(ic, stage);
+            if (stream_w) issue_weights(ic, stage);
+            if (++ic == p.nchunks) {
+                ic = 0; it += tstride;
+                if (it < tend) setup_voff(it);
             }
-            if (tn >= tend) break;
-            t = tn;
+        };
+        const int ahead = min(D - 1, nsteps);
+        for (int s = 0; s < ahead; ++s) issue_next(s);
+        for (int s = 0; s < nsteps; ++s) {
+            const int inflight = min(D - 2, nsteps - 1 - s);
+            WaitVm<63>::go(min(63, inflight * per_step));
+            __builtin_amdgcn_s_barrier();
+            if (s + D - 1 < nsteps) issue_next(s + D - 1);
         }
         return;
     }
 
     // =================== compute waves: MFMA + epilogue ===================
     const int wn = wave % WN, wm = wave / WN;
+    const int fpy = FOLD ? (wn >> 1) : 0, fpx = FOLD ? (wn & 1) : 0;       // fold: this wave's output phase
     // MFMA pixel operand: m-tile m, lane l -> tile pixel pp = 16m + (l & 15) of this wave's 4 x 20 rows
     int xa[MREP][3], ry[MREP], rx[MREP];
 #pragma unroll
@@ -181,7 +217,8 @@ __global__ __launch_bounds__(512) void conv3_pk(const ConvParams p) {
         ry[m] = wm * PK_ROWS + py; rx[m] = px;
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) {
-            const int s = ry[m] * PK_PWP + px + dx;
+            // fold: window column b (= dx < 2) of phase column fpx is patch column px + fpx + b, window row a is patch row py + fpy + a
+            const int s = (ry[m] + fpy) * PK_PWP + px + fpx + dx;
             xa[m][dx] = (s * 64 + (lane >> 4) * 16) ^ ((s & 4) << 3);
         }
     }
@@ -192,6 +229,9 @@ __global__ __launch_bounds__(512) void conv3_pk(const ConvParams p) {
     int b, oy0, ox0;
     tile_coords(t, b, oy0, ox0);
     int step = 0;
+    // fused stage operands that are the same for every tile: loaded once per launch (fold only; the other fused ops run per tile)
+    Stage2Regs<T, NREP, NREP2 ? NREP2 : 1> s2r;
+    if constexpr (FOLD) stage2_preload<T, NREP, NREP2>(p, lane, true, s2r);
     VTI_STAMP(0);
     while (true) {
         f32x4 acc[MREP][NREP];
@@ -200,21 +240,22 @@ __global__ __launch_bounds__(512) void conv3_pk(const ConvParams p) {
 #pragma unroll
             for (int n = 0; n < NREP; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
         for (int c = 0; c < p.nchunks; ++c, ++step) {
-            const int cur = step & 1;
+            const int cur = step % D;
             __builtin_amdgcn_s_barrier();               // the loaders waited for DMA(step) before they arrived
             asm volatile("" ::: "memory");
             if (step < 2) VTI_STAMP(1 + 4 * step);
             // ---- MFMA over the 9 taps of this chunk (software pipelined as in conv.hip)
             {
                 const char* sx = smem + cur * stage_bytes;
-                const char* sw = smem + wbuf_off + (p.nchunks > 1 ? cur : 0) * WCHUNK + wn * (NREP * TAPS * 1024) + lane * 16;
+                const char* sw = smem + wbuf_off + (stream_w ? cur : c) * WCHUNK + wn * (NREP * TAPS * 1024) + lane * 16;
                 constexpr int NSTEP = TAPS * MREP;
                 constexpr int XD = 3, WD = 2;
                 vec xq[XD];
                 vec wq[WD][NREP];
                 auto ldx = [&](int s_) -> vec {
                     const int tp = s_ / MREP, mm = s_ % MREP;
-                    return *(const vec*)(sx + xa[mm][tp % 3] + (tp / 3) * (PK_PWP * 64));
+                    if constexpr (FOLD) return *(const vec*)(sx + xa[mm][tp & 1] + (tp >> 1) * (PK_PWP * 64));
+                    else return *(const vec*)(sx + xa[mm][tp % 3] + (tp / 3) * (PK_PWP * 64));
                 };
                 auto ldw = [&](int tp, vec (&w)[NREP]) {
 #pragma unroll
@@ -335,7 +376,13 @@ __global__ __launch_bounds__(512) void conv3_pk(const ConvParams p) {
                 opy[m] = oy0 + ry[m]; opx[m] = ox0 + rx[m];
                 pvalid[m] = opy[m] < p.Hout && opx[m] < p.Wout;
             }
-            if constexpr (NREP2 == 0) conv_epilogue<T, NREP>(p, acc, pvalid, opy, opx, b, nt0, wn, lane);
+            if constexpr (FOLD) {
+#pragma unroll
+                for (int m = 0; m < MREP; ++m) { opy[m] = 2 * opy[m] + fpy; opx[m] = 2 * opx[m] + fpx; }
+                // no pixel of an interior tile lies on the first / last output row or column: one bias vector for all of them
+                const bool interior = oy0 > 0 && oy0 + p.TH < p.Hout && ox0 > 0 && ox0 + PK_TW < p.Wout;
+                conv_stage2<T, NREP, NREP2, true, true>(p, acc, pvalid, opy, opx, b, lane, &s2r, interior);
+            } else if constexpr (NREP2 == 0) conv_epilogue<T, NREP>(p, acc, pvalid, opy, opx, b, nt0, wn, lane);
             else conv_stage2<T, NREP, NREP2>(p, acc, pvalid, opy, opx, b, lane);
         }
         VTI_STAMP(12);
@@ -357,8 +404,6 @@ __global__ __launch_bounds__(512) void conv3_pk(const ConvParams p) {
 //  * weights stay in LDS for the whole launch when all K chunks of the workgroup's n-group fit (`pk_wstat`),
 //    otherwise the chunk of a step travels with its pixels in the ring.
 // One raw s_barrier per (tile, chunk) step.
-template <int N> struct WaitVm { static __device__ __forceinline__ void go(int n) { if (n >= N) wait_vm<N>(); else WaitVm<N - 1>::go(n); } };
-template <> struct WaitVm<0> { static __device__ __forceinline__ void go(int) { wait_vm<0>(); } };
 
 constexpr int PK1_MAXP = 5;       // pixel DMA pieces per loader wave and step (80 px = 5 pieces per M-wave, WN >= 1)
 
@@ -587,9 +632,9 @@ __global__ __launch_bounds__(512) void conv1_pk(const ConvParams p) {
     }
 }
 
-template <typename T, int NREP, int WN, int NREP2 = 0>
+template <typename T, int NREP, int WN, int NREP2 = 0, bool FOLD = false>
 static hipError_t launch_pk_one(const ConvParams& p, dim3 grid, int threads, size_t lds, hipStream_t st) {
-    auto k = conv3_pk<T, NREP, WN, NREP2>;
+    auto k = conv3_pk<T, NREP, WN, NREP2, FOLD>;
     static bool attr_done_dev[kMaxDevices] = {};
     bool& attr_done = attr_done_dev[current_device_slot()];
     if (!attr_done) {
@@ -667,10 +712,38 @@ hipError_t launch_conv1_pk(int dtype, int nrep, const ConvParams& p, size_t lds_
     return launch_pk1_t<float>(nrep, p, grid, threads, lds_bytes, st);
 }
 
+// fold on the persistent schedule: 4 x 20 low-resolution pixels per tile, 4 phase waves + 4 loader waves, 2 stages of a 6 x 24 slot
+// patch + both K chunks of the composed weights (2 x 16 n-tiles x 4 taps KiB) + the (unused) bias slot
+size_t conv_pk_fold_lds_bytes(int nchunks, int depth) { return depth * (size_t)6 * PK_PWP * 64 + (size_t)(nchunks > 1 ? 2 : 1) * 16 * 4 * 1024 + 16 * 16 * 4; }
+int conv_pk_fold_depth(int nchunks) {
+    const char* cap = getenv("VTI_PK_DEPTH");
+    const int maxd = cap ? std::max(2, std::min(4, atoi(cap))) : 4;
+    int d = 2;
+    while (d < maxd && conv_pk_fold_lds_bytes(nchunks, d + 1) <= 160 * 1024) ++d;
+    return d;
+}
+
+hipError_t launch_conv_pk_fold(int dtype, const ConvParams& p, size_t lds_bytes, hipStream_t st) {
+    if (p.TH != 4 || p.TW != PK_TW || p.WN != 4 || p.nchunks > 2 || p.ntiles_n != 16 || !p.fold || !p.out2) return hipErrorInvalidValue;
+    if (p.pk_wgs < 1 || (p.pk_xcd && p.pk_wgs % 8) || (size_t)p.in_bytes >= 0x80000000u) return hipErrorInvalidValue;
+    if (p.pk_depth < 2 || p.pk_depth > 4 || lds_bytes < conv_pk_fold_lds_bytes(p.nchunks, p.pk_depth) || lds_bytes > 160 * 1024) return hipErrorInvalidValue;
+    if (p.pk_tiles == 0) return hipSuccess;
+    dim3 grid((unsigned)p.pk_wgs, 1);
+#define VTI_FP(N2)                                                                                              \
+    if (p.ntiles2 == N2) {                                                                                      \
+        if (dtype == VTI_F16) return launch_pk_one<half_t, 4, 4, N2, true>(p, grid, 512, lds_bytes, st);        \
+        return launch_pk_one<float, 4, 4, N2, true>(p, grid, 512, lds_bytes, st);                               \
+    }
+    VTI_FP(1) VTI_FP(2) VTI_FP(4)
+#undef VTI_FP
+    return hipErrorInvalidValue;
+}
+
 // grid.x workgroups (p.pk_wgs, a multiple of 8 when p.pk_xcd) x n-groups; (TH/4) * WN compute + as many loader waves
 hipError_t launch_conv_pk(int dtype, int nrep, const ConvParams& p, size_t lds_bytes, hipStream_t st) {
     const int NTB = p.WN * nrep;
     if (p.TH % PK_ROWS || p.TW != PK_TW || !conv_pk_fits(p.TH, p.WN, nrep, p.nchunks)) return hipErrorInvalidValue;
+    if (p.pk_depth < 2 || p.pk_depth > 4 || lds_bytes < conv_pk_lds_bytes(p.TH, p.WN, nrep, p.nchunks, p.pk_depth) || lds_bytes > 160 * 1024) return hipErrorInvalidValue;
     if (p.ntiles_n % NTB || p.pk_wgs < 1 || (p.pk_xcd && p.pk_wgs % 8)) return hipErrorInvalidValue;
     if ((size_t)p.in_bytes >= 0x80000000u || (size_t)p.out_bytes >= 0x80000000u) return hipErrorInvalidValue;
     if (p.pk_tiles == 0) return hipSuccess;
@@ -678,6 +751,349 @@ hipError_t launch_conv_pk(int dtype, int nrep, const ConvParams& p, size_t lds_b
     dim3 grid((unsigned)p.pk_wgs, (unsigned)(p.ntiles_n / NTB));
     if (dtype == VTI_F16) return launch_pk_t<half_t>(nrep, p, grid, threads, lds_bytes, st);
     return launch_pk_t<float>(nrep, p, grid, threads, lds_bytes, st);
+}
+
+// =====================================================================================================
+// Fused C2f Bottleneck (Ultralytics Bottleneck(c, c, shortcut, k=(3,3), e=1.0): SURVEY section 8 U2): y = [x +] silu(W2 * silu(W1 * x + b1) + b2)
+// in ONE persistent kernel -- the 3x3 -> 3x3 pair of model.{2,4,15,...}.m.j.  The intermediate tensor lives only as a (TH+2) x 22
+// tile in LDS (halo recompute: conv 1 runs on the tile grown by one pixel, 7 instead of 5 m-tiles per wave), the shortcut is read
+// from the input patch that is in LDS anyway, so per pair one read of x (+ halo) and one write of y reach memory instead of
+// x, t, t, x, y.  Channel counts of one K chunk (C <= 32 fp16 / 16 fp32: the 160x160 and 80x80 blocks of the n model, where
+// these layers are HBM-bound); both convs' weights stay in LDS for the whole launch.
+//   * loader waves (as many as compute waves): patch (TH+4) x 24 slots of tile t+1 by LDS-DMA into the other stage while tile t computes
+//   * compute wave wm, phase 1: conv 1 on R1 pixels [112 wm, 112 wm + 112) of the (TH+2) x 22 region, bias + SiLU, rounded to T and
+//     written to the T image (same swizzled 64-B pixel slots as a DMA'd patch; pixels outside the feature map are conv 2's ZERO padding)
+//   * barrier; phase 2: conv 2 on its 4 x 20 pixels from the T image, bias + SiLU (+ shortcut from the input stage), 16-byte stores
+// Two workgroup barriers per tile.  ConvParams: wpk/bias = conv 1, w2/bias2 = conv 2; res must be the input view when has_res.
+constexpr int BN_MREP1 = 7;
+
+size_t bneck_pk_lds_bytes(int TH, int NREP) {
+    return 2 * (size_t)(TH + 4) * PK_PWP * 64 + (size_t)(TH + 2) * PK_PWP * 64 + 2 * (size_t)NREP * 9 * 1024 + 2 * (size_t)NREP * 64;
+}
+bool bneck_pk_fits(int TH, int NREP) {
+    if (TH % PK_ROWS || TH < 8 || TH > 16 || NREP < 1 || NREP > 2) return false;
+    const int nwm = TH / PK_ROWS;
+    if (((TH + 2) * (PK_TW + 2) + 15) / 16 > BN_MREP1 * nwm) return false;          // conv-1 m-tiles per wave
+    if (((TH + 4) * PK_PWP / 16 + nwm - 1) / nwm > PK_MAXD) return false;            // patch DMA pieces per loader wave
+    return bneck_pk_lds_bytes(TH, NREP) <= 160 * 1024;
+}
+
+template <typename T, int NREP>
+__global__ __launch_bounds__(512) void bneck_pk(const ConvParams p) {
+    using vec = typename Tr<T>::vec;
+    constexpr int VEC = Tr<T>::VEC, ES = (int)sizeof(T);
+    constexpr int TAPS = 9, R1W = PK_TW + 2;
+    constexpr unsigned OOB = 0x80000000u;
+    constexpr bool FAST = sizeof(T) == 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nwm = p.TH / PK_ROWS;                         // compute waves; as many loader waves
+    const int PH = p.TH + 4, R1H = p.TH + 2;
+    const int stage_bytes = PH * PK_PWP * 64;
+    const int timg_off = 2 * stage_bytes;
+    const int w1_off = timg_off + R1H * PK_PWP * 64;
+    const int w2_off = w1_off + NREP * TAPS * 1024;
+    const int bias_off = w2_off + NREP * TAPS * 1024;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+
+    for (int i = tid; i < NREP * 16; i += (int)blockDim.x) {
+        ((float*)(smem + bias_off))[i] = p.bias[i];
+        ((float*)(smem + bias_off))[NREP * 16 + i] = p.bias2[i];
+    }
+    for (int i = tid; i < R1H * PK_PWP * 4; i += (int)blockDim.x) ((f32x4*)(smem + timg_off))[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+
+    int t, tend, tstride;
+    if (p.pk_xcd) {
+        const int per = (p.pk_tiles + 7) >> 3, k = blockIdx.x & 7;
+        t = k * per + (int)(blockIdx.x >> 3);
+        tend = min((k + 1) * per, p.pk_tiles);
+        tstride = (int)(gridDim.x >> 3);
+    } else {
+        t = blockIdx.x; tend = p.pk_tiles; tstride = (int)gridDim.x;
+    }
+    if (t >= tend) return;
+    auto tile_coords = [&](int tt, int& b, int& oy0, int& ox0) {
+        const int tx = tt % p.tiles_x, r = tt / p.tiles_x;
+        const int ty = r % p.tiles_y;
+        b = r / p.tiles_y; oy0 = ty * p.TH; ox0 = tx * PK_TW;
+    };
+
+    if (wave >= nwm) {
+        // =================== loader waves ===================
+        const int lw = wave - nwm, nld = nwm;
+        const int ndma = PH * PK_PWP / 16;
+        const int q = (lane & 3) ^ (((lane >> 4) & 1) << 1);
+        const bool qok = q * VEC < p.Cin;                   // one chunk: channel pieces beyond Cin are written as zeros
+        int dyx[PK_MAXD];
+#pragma unroll
+        for (int u = 0; u < PK_MAXD; ++u) {
+            const int s = (lw + u * nld) * 16 + (lane >> 2);
+            const int py = (int)(((unsigned)s * 2731u) >> 16), px = s - py * PK_PWP;
+            dyx[u] = (py << 8) | px;                        // every column of the 24-slot row is a patch pixel here (20 + 2 x 2 halo)
+        }
+        const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)p.in_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsW1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.wpk, 0, NREP * TAPS * 1024, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsW2 = __builtin_amdgcn_make_buffer_rsrc((void*)p.w2, 0, NREP * TAPS * 1024, 0x00020000);
+        auto issue_patch = [&](int tt, int stage) {
+            int b, oy0, ox0;
+            tile_coords(tt, b, oy0, ox0);
+            const unsigned dst = lds0 + stage * stage_bytes + lw * 1024;
+#pragma unroll
+            for (int u = 0; u < PK_MAXD; ++u) {
+                if (lw + u * nld >= ndma) break;
+                const int y = oy0 - 2 + (dyx[u] >> 8), x = ox0 - 2 + (dyx[u] & 255);
+                const bool ok = qok && (unsigned)y < (unsigned)p.Hin && (unsigned)x < (unsigned)p.Win;
+                const unsigned vo = ok ? (unsigned)((((b * p.Hin + y) * p.Win + x) * p.in_ld + p.in_coff + q * VEC) * ES) : OOB;
+                dma16(rsA, vo, 0u, dst + u * nld * 1024);
+            }
+        };
+        for (int f = lw; f < NREP * TAPS; f += nld) {
+            dma16(rsW1, (unsigned)lane * 16u, (unsigned)(f * 1024), lds0 + w1_off + f * 1024);
+            dma16(rsW2, (unsigned)lane * 16u, (unsigned)(f * 1024), lds0 + w2_off + f * 1024);
+        }
+        issue_patch(t, 0);
+        int step = 0;
+        while (true) {
+            wait_vm<0>();
+            __builtin_amdgcn_s_barrier();                   // A: patch(step) has landed; every compute wave left the other stage and the T image
+            const int tn = t + tstride;
+            if (tn < tend) issue_patch(tn, (step + 1) & 1);
+            __builtin_amdgcn_s_barrier();                   // B
+            if (tn >= tend) break;
+            t = tn; ++step;
+        }
+        return;
+    }
+
+    // =================== compute waves ===================
+    const int wm = wave;
+    // phase 1 operand addresses: R1 pixel pp -> (r1y, r1x); patch slot of tap (dy, dx) = (r1y + dy) * 24 + r1x + dx
+    int xa1[BN_MREP1][3], r1y[BN_MREP1], r1x[BN_MREP1];
+    bool v1[BN_MREP1];
+    int tw1[BN_MREP1];                                      // T-image byte address of this lane's channel run
+#pragma unroll
+    for (int m = 0; m < BN_MREP1; ++m) {
+        const int pp = (wm * BN_MREP1 + m) * 16 + (lane & 15);
+        v1[m] = pp < R1H * R1W;
+        const int pc = v1[m] ? pp : 0;
+        const int yy = (int)(((unsigned)pc * 2979u) >> 16), xx = pc - yy * R1W;      // pc / 22 for pc < 8192
+        r1y[m] = yy; r1x[m] = xx;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int s = yy * PK_PWP + xx + dx;
+            xa1[m][dx] = (s * 64 + g * 16) ^ ((s & 4) << 3);
+        }
+        const int st = yy * PK_PWP + xx;
+        // lane group g owns channels 4 NREP g ..: fp16 NREP 2 / fp32 -> 16-byte piece g; fp16 NREP 1 -> half of piece g >> 1
+        const int piece = (sizeof(T) == 2 && NREP == 1) ? (g >> 1) : g;
+        tw1[m] = timg_off + ((st * 64 + piece * 16) ^ ((st & 4) << 3)) + ((sizeof(T) == 2 && NREP == 1) ? (g & 1) * 8 : 0);
+    }
+    // phase 2 operand addresses (as conv3_pk, on the T image whose origin is the tile origin - 1)
+    int xa2[MREP][3], ry[MREP], rx[MREP], ra[MREP];
+#pragma unroll
+    for (int m = 0; m < MREP; ++m) {
+        const int pp = m * 16 + (lane & 15);
+        const int py = (pp * 205) >> 12, px = pp - py * PK_TW;
+        ry[m] = wm * PK_ROWS + py; rx[m] = px;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int s = ry[m] * PK_PWP + px + dx;
+            xa2[m][dx] = timg_off + ((s * 64 + g * 16) ^ ((s & 4) << 3));
+        }
+        const int sr = (ry[m] + 2) * PK_PWP + px + 2;       // the pixel itself in the input patch (shortcut)
+        const int piece = (sizeof(T) == 2 && NREP == 1) ? (g >> 1) : g;
+        ra[m] = ((sr * 64 + piece * 16) ^ ((sr & 4) << 3)) + ((sizeof(T) == 2 && NREP == 1) ? (g & 1) * 8 : 0);
+    }
+    const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)p.out_bytes, 0x00020000);
+    const int crun = g * 4 * NREP;
+    f32x4 b1r[NREP], b2r[NREP];
+#pragma unroll
+    for (int n = 0; n < NREP; ++n) {
+        b1r[n] = *(const f32x4*)(smem + bias_off + (crun + 4 * n) * 4);
+        b2r[n] = *(const f32x4*)(smem + bias_off + (NREP * 16 + crun + 4 * n) * 4);
+    }
+    const bool has_res = __builtin_amdgcn_readfirstlane(p.has_res) != 0;
+    int step = 0;
+    while (true) {
+        int b, oy0, ox0;
+        tile_coords(t, b, oy0, ox0);
+        const char* sx = smem + (step & 1) * stage_bytes;
+        __builtin_amdgcn_s_barrier();                       // A
+        asm volatile("" ::: "memory");
+        // ---- phase 1: conv 1 on the grown tile
+        {
+            f32x4 acc[BN_MREP1][NREP];
+#pragma unroll
+            for (int m = 0; m < BN_MREP1; ++m)
+#pragma unroll
+                for (int n = 0; n < NREP; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const char* sw = smem + w1_off + lane * 16;
+            constexpr int NSTEP = TAPS * BN_MREP1;
+            vec xq[3];
+            vec wq[2][NREP];
+            auto ldx = [&](int s_) -> vec {
+                const int tp = s_ / BN_MREP1, mm = s_ % BN_MREP1;
+                return *(const vec*)(sx + xa1[mm][tp % 3] + (tp / 3) * (PK_PWP * 64));
+            };
+            auto ldw = [&](int tp, vec (&w)[NREP]) {
+#pragma unroll
+                for (int n = 0; n < NREP; ++n) w[n] = *(const vec*)(sw + (n * TAPS + tp) * 1024);
+            };
+            ldw(0, wq[0]);
+            xq[0] = ldx(0);
+            xq[1] = ldx(1);
+#pragma unroll
+            for (int s_ = 0; s_ < NSTEP; ++s_) {
+                const int tp = s_ / BN_MREP1, mm = s_ % BN_MREP1;
+                if (s_ + 2 < NSTEP) xq[(s_ + 2) % 3] = ldx(s_ + 2);
+                if (mm == 0 && tp + 1 < TAPS) ldw(tp + 1, wq[(tp + 1) % 2]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int n = 0; n < NREP; ++n) acc[mm][n] = mma(wq[tp % 2][n], xq[s_ % 3], acc[mm][n]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // bias + SiLU, rounded to T, into the T image; a pixel outside the feature map is conv 2's zero padding
+#pragma unroll
+            for (int m = 0; m < BN_MREP1; ++m) {
+                const int gy = oy0 - 1 + r1y[m], gx = ox0 - 1 + r1x[m];
+                const bool inside = (unsigned)gy < (unsigned)p.Hout && (unsigned)gx < (unsigned)p.Wout;
+                f32x4 v[NREP];
+#pragma unroll
+                for (int n = 0; n < NREP; ++n) {
+                    v[n] = silu4<FAST>(acc[m][n] + b1r[n]);
+                    if (!inside) v[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+                if (!v1[m]) continue;
+                if constexpr (sizeof(T) == 2 && NREP == 2) {
+                    half8 hv;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { hv[j] = (half_t)v[0][j]; hv[4 + j] = (half_t)v[1][j]; }
+                    *(half8*)(smem + tw1[m]) = hv;
+                } else if constexpr (sizeof(T) == 2) {
+                    half4 hv;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) hv[j] = (half_t)v[0][j];
+                    *(half4*)(smem + tw1[m]) = hv;
+                } else {
+                    static_assert(sizeof(T) == 2 || NREP == 1, "fp32: one 16-channel chunk");
+                    *(f32x4*)(smem + tw1[m]) = v[0];
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's T-image writes have been performed (a raw s_barrier does not wait)
+        __builtin_amdgcn_s_barrier();                       // B: the T image is complete
+        asm volatile("" ::: "memory");
+        // ---- phase 2: conv 2 on the tile, from the T image
+        {
+            f32x4 acc[MREP][NREP];
+#pragma unroll
+            for (int m = 0; m < MREP; ++m)
+#pragma unroll
+                for (int n = 0; n < NREP; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const char* sw = smem + w2_off + lane * 16;
+            constexpr int NSTEP = TAPS * MREP;
+            vec xq[3];
+            vec wq[2][NREP];
+            auto ldx = [&](int s_) -> vec {
+                const int tp = s_ / MREP, mm = s_ % MREP;
+                return *(const vec*)(smem + xa2[mm][tp % 3] + (tp / 3) * (PK_PWP * 64));
+            };
+            auto ldw = [&](int tp, vec (&w)[NREP]) {
+#pragma unroll
+                for (int n = 0; n < NREP; ++n) w[n] = *(const vec*)(sw + (n * TAPS + tp) * 1024);
+            };
+            ldw(0, wq[0]);
+            xq[0] = ldx(0);
+            xq[1] = ldx(1);
+#pragma unroll
+            for (int s_ = 0; s_ < NSTEP; ++s_) {
+                const int tp = s_ / MREP, mm = s_ % MREP;
+                if (s_ + 2 < NSTEP) xq[(s_ + 2) % 3] = ldx(s_ + 2);
+                if (mm == 0 && tp + 1 < TAPS) ldw(tp + 1, wq[(tp + 1) % 2]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int n = 0; n < NREP; ++n) acc[mm][n] = mma(wq[tp % 2][n], xq[s_ % 3], acc[mm][n]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int m = 0; m < MREP; ++m) {
+                const int gy = oy0 + ry[m], gx = ox0 + rx[m];
+                const bool pv = gy < p.Hout && gx < p.Wout;
+                const int opix = (b * p.Hout + gy) * p.Wout + gx;
+                const unsigned ob = (unsigned)((opix * p.out_ld + p.out_coff + crun) * ES);
+                f32x4 v[NREP];
+#pragma unroll
+                for (int n = 0; n < NREP; ++n) v[n] = silu4<FAST>(acc[m][n] + b2r[n]);
+                if (has_res) {                              // the shortcut: this pixel of the input patch, still in its stage
+                    if constexpr (sizeof(T) == 2 && NREP == 2) {
+                        const half8 r = *(const half8*)(sx + ra[m]);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { v[0][j] += (float)r[j]; v[1][j] += (float)r[4 + j]; }
+                    } else if constexpr (sizeof(T) == 2) {
+                        const half4 r = *(const half4*)(sx + ra[m]);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[0][j] += (float)r[j];
+                    } else {
+                        v[0] += *(const f32x4*)(sx + ra[m]);
+                    }
+                }
+                if constexpr (sizeof(T) == 2 && NREP == 2) {
+                    half8 hv;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { hv[j] = (half_t)v[0][j]; hv[4 + j] = (half_t)v[1][j]; }
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hv), rsO, pv ? ob : OOB, 0u, 0);
+                } else if constexpr (sizeof(T) == 2) {
+                    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                    half4 hv;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) hv[j] = (half_t)v[0][j];
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hv), rsO, pv ? ob : OOB, 0u, 0);
+                } else {
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[0]), rsO, pv ? ob : OOB, 0u, 0);
+                }
+            }
+        }
+        const int tn = t + tstride;
+        if (tn >= tend) break;
+        t = tn; ++step;
+    }
+}
+
+template <typename T, int NREP>
+static hipError_t launch_bneck_one(const ConvParams& p, dim3 grid, int threads, size_t lds, hipStream_t st) {
+    auto k = bneck_pk<T, NREP>;
+    static bool done_dev[kMaxDevices] = {};
+    bool& done = done_dev[current_device_slot()];
+    if (!done) {
+        hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        done = true;
+    }
+    hipLaunchKernelGGL(k, grid, dim3(threads), lds, st, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_bneck_pk(int dtype, int nrep, const ConvParams& p, size_t lds_bytes, hipStream_t st) {
+    if (p.TW != PK_TW || !bneck_pk_fits(p.TH, nrep) || p.nchunks != 1 || p.Cin != 16 * nrep || p.Cout != 16 * nrep || !p.w2 || !p.bias2)
+        return hipErrorInvalidValue;
+    if (p.Hin != p.Hout || p.Win != p.Wout || p.pk_wgs < 1 || (p.pk_xcd && p.pk_wgs % 8)) return hipErrorInvalidValue;
+    if ((size_t)p.in_bytes >= 0x80000000u || (size_t)p.out_bytes >= 0x80000000u) return hipErrorInvalidValue;
+    if (p.has_res && (p.res != p.in || p.res_ld != p.in_ld || p.res_coff != p.in_coff)) return hipErrorInvalidValue;   // shortcut = the input
+    if ((p.out_ld | p.out_coff) & (dtype == VTI_F16 ? 7 : 3)) return hipErrorInvalidValue;                              // 16-byte stores
+    if (lds_bytes < bneck_pk_lds_bytes(p.TH, nrep)) return hipErrorInvalidValue;
+    if (p.pk_tiles == 0) return hipSuccess;
+    const int threads = 2 * (p.TH / PK_ROWS) * 64;
+    dim3 grid((unsigned)p.pk_wgs, 1);
+    if (dtype == VTI_F16) {
+        if (nrep == 1) return launch_bneck_one<half_t, 1>(p, grid, threads, lds_bytes, st);
+        if (nrep == 2) return launch_bneck_one<half_t, 2>(p, grid, threads, lds_bytes, st);
+    } else if (nrep == 1) {
+        return launch_bneck_one<float, 1>(p, grid, threads, lds_bytes, st);
+    }
+    return hipErrorInvalidValue;
 }
 
 }  // namespace vti

@@ -142,7 +142,16 @@ static bool choose_pk_cfg(int esize, const ConvRow& r, int max_batch, ConvCfg& c
             }
         }
     }
-    if (found) c.ntiles_n = (c.ntiles_n + c.WN * c.NREP - 1) / (c.WN * c.NREP) * (c.WN * c.NREP);   // whole workgroup n-groups
+    if (found) {
+        c.ntiles_n = (c.ntiles_n + c.WN * c.NREP - 1) / (c.WN * c.NREP) * (c.WN * c.NREP);   // whole workgroup n-groups
+        // ring depth: a deeper ring (loaders further ahead) when it costs no co-resident workgroup
+        c.pk_depth = 2;
+        const int dmax = conv_pk_depth(c.TH, c.WN, c.NREP, c.nchunks);
+        for (int dd = 3; dd <= dmax; ++dd) {
+            const size_t l = conv_pk_lds_bytes(c.TH, c.WN, c.NREP, c.nchunks, dd);
+            if ((int)std::min<size_t>(2, (160 * 1024) / l) >= c.pk_wgpc) { c.pk_depth = dd; c.lds = l; }
+        }
+    }
     return found;
 }
 
@@ -456,6 +465,39 @@ std::string Plan::build(const vti_desc& d) {
         }
     }
 
+    // Fuse the two 3x3 convs of a C2f Bottleneck (m.j.cv1 -> m.j.cv2 [+ shortcut]) into one persistent kernel when their channels
+    // fit one K chunk (bneck_pk: the intermediate lives in LDS, the shortcut comes from the input patch).
+    {
+        const char* nb = getenv("VTI_NO_BNECK");
+        const int KC = d.dtype == VTI_F16 ? 32 : 16;
+        size_t pk_limit = 0x80000000ull;
+        if (const char* pl = getenv("VTI_PK_LIMIT_BYTES")) pk_limit = (size_t)atoll(pl);
+        for (size_t i = 0; !(nb && nb[0] == '1') && i + 1 < ops.size(); ++i) {
+            Op& a = ops[i];
+            const Op& b2 = ops[i + 1];
+            if (a.kind != OP_CONV || b2.kind != OP_CONV || a.lane != b2.lane || a.fused >= 0 || b2.fused >= 0 || a.fold >= 0 || b2.fold >= 0) continue;
+            const ConvRow& ra = convs[a.conv];
+            const ConvRow& rb = convs[b2.conv];
+            if (!(ra.k == 3 && ra.s == 1 && ra.kind == 0 && rb.k == 3 && rb.s == 1 && rb.kind == 0)) continue;
+            if (ra.c1 != ra.c2 || rb.c1 != rb.c2 || ra.c1 != rb.c1 || ra.c1 % 16 || ra.c1 > KC || ra.c1 > 32) continue;
+            if (a.has_res || a.out_f32 || b2.out_f32 || ra.w_out < 20 || ra.h_out < 8) continue;
+            if (b2.in.buf != a.out.buf || b2.in.coff != a.out.coff || b2.in.C != a.out.C || a.out.C != bufs[a.out.buf].C) continue;
+            if (b2.has_res && (b2.res.buf != a.in.buf || b2.res.coff != a.in.coff || b2.res.C != a.in.C)) continue;
+            if (bufs[a.in.buf].bytes >= pk_limit || bufs[b2.out.buf].bytes >= pk_limit) continue;
+            const int esz = d.dtype == VTI_F16 ? 2 : 4;
+            if (((bufs[b2.out.buf].C | b2.out.coff) * esz) % 16) continue;        // 16-byte stores of a lane's channel run
+            bool other_reader = false;
+            for (size_t j = 0; j < ops.size(); ++j)
+                if (j != i + 1 && (ops[j].kind == OP_CONV || ops[j].kind == OP_UP2 || ops[j].kind == OP_POOL) &&
+                    (ops[j].in.buf == a.out.buf || (ops[j].has_res && ops[j].res.buf == a.out.buf))) other_reader = true;
+            if (other_reader) continue;
+            a.pair = b2.conv;
+            a.out = b2.out; a.has_res = b2.has_res; a.res = b2.res;
+            conv_out[a.conv].buf = -1;          // the intermediate is never materialised
+            ops.erase(ops.begin() + i + 1);
+        }
+    }
+
     // stem + layer 1 in one kernel (n-scale channel counts: 3 -> 16 -> 32): the 320x320x16 tensor stays in LDS
     {
         const char* nsf = getenv("VTI_NO_STEM_FUSE");
@@ -557,7 +599,19 @@ std::string Plan::build(const vti_desc& d) {
         if (const char* pl = getenv("VTI_PK_LIMIT_BYTES")) pk_limit = (size_t)atoll(pl);
         const bool pk_ok = bufs[op.in.buf].bytes < pk_limit && bufs[op.out.buf].bytes < pk_limit &&
                            (!op.has_res || bufs[op.res.buf].bytes < pk_limit);
-        if (op.fold >= 0) {         // convfold_kernel: 4 x 20 low-resolution pixels per workgroup, wave = output phase, 4 n-tiles each
+        if (op.pair >= 0) {         // bneck_pk: 16 x 20 tiles (4 compute + 4 loader waves); 8 x 20 when that leaves CUs without a tile
+            const ConvRow& rb = convs[op.pair];
+            macs += rb.macs(); fused_params += rb.fused_params();
+            const int KC = d.dtype == VTI_F16 ? 32 : 16;
+            op.cfg = ConvCfg();
+            const long tiles16 = (long)d.max_batch * ((r.h_out + 15) / 16) * ((r.w_out + 19) / 20);
+            op.cfg.TH = tiles16 >= 256 ? 16 : 8; op.cfg.TW = 20; op.cfg.WN = 1; op.cfg.NREP = r.c2 / 16;
+            op.cfg.nchunks = (r.c1 + KC - 1) / KC; op.cfg.gemm_n = r.c2; op.cfg.ntiles_n = r.c2 / 16;
+            op.cfg.pk = 3; op.cfg.pk_wgpc = 1;
+            op.cfg.lds = bneck_pk_lds_bytes(op.cfg.TH, op.cfg.NREP);
+            if (!bneck_pk_fits(op.cfg.TH, op.cfg.NREP) || op.cfg.nchunks != 1) return "no launch configuration for the fused bottleneck " + r.name;
+        }
+        else if (op.fold >= 0) {         // convfold_kernel: 4 x 20 low-resolution pixels per workgroup, wave = output phase, 4 n-tiles each
             const ConvRow& ru = convs[op.fold];
             macs += ru.macs(); fused_params += ru.fused_params();
             const int KC = d.dtype == VTI_F16 ? 32 : 16;
@@ -565,6 +619,10 @@ std::string Plan::build(const vti_desc& d) {
             op.cfg.TH = 4; op.cfg.TW = 20; op.cfg.WN = 4; op.cfg.NREP = r.c2 / 16;
             op.cfg.nchunks = (ru.c1 + KC - 1) / KC; op.cfg.gemm_n = 4 * r.c2; op.cfg.ntiles_n = 4 * (r.c2 / 16);
             op.cfg.lds = convfold_lds_bytes(op.cfg.TH, op.cfg.TW);
+            // persistent schedule (weights stay in LDS): fp16 only (the fp32 engine's 4 chunks of 64 KB do not fit), tensors < 2 GiB
+            const char* npf = getenv("VTI_NO_PK_FOLD");
+            if (pk_ok && op.cfg.nchunks <= 2 && !(npf && npf[0] == '1')) { op.cfg.pk = 1; op.cfg.pk_wgpc = 1; op.cfg.pk_depth = conv_pk_fold_depth(op.cfg.nchunks);
+                                                                          op.cfg.lds = conv_pk_fold_lds_bytes(op.cfg.nchunks, op.cfg.pk_depth); }
         }
         else if (op.fused_l1 >= 0) choose_conv_cfg(d.dtype, r, true, d.max_batch, op.cfg, 0, 0, 1, 1);   // one 16-channel n-tile: stem_l1_kernel's weight indexing
         else if (op.fused >= 0) {   // whole Cout in one wave; the per-tile kernel (2 workgroups per CU) hides the long fused epilogue better
@@ -578,6 +636,11 @@ std::string Plan::build(const vti_desc& d) {
         op.cfg.bias_off = boff;
         if (op.fold >= 0) { woff += packed_fold_bytes(op.cfg); boff += (size_t)9 * r.c2; }      // bias: [3 x 3 border classes][Cout]
         else { woff += packed_conv_bytes(r, op.kind == OP_CONV0, op.cfg); boff += (size_t)op.cfg.ntiles_n * 16; }
+        if (op.pair >= 0) {         // second conv of the pair: the same packing, its own slot
+            op.cfg.wpk_off2 = woff; op.cfg.bias_off2 = boff;
+            woff += packed_conv_bytes(convs[op.pair], false, op.cfg);
+            boff += (size_t)op.cfg.ntiles_n * 16;
+        }
         if (op.fused_l1 >= 0) {
             const ConvRow& r1 = convs[op.fused_l1];
             macs += r1.macs(); fused_params += r1.fused_params();

@@ -116,9 +116,12 @@ int32_t vti_conv_at(const vti_ctx* c, int32_t i, vti_conv_info* o) {
         if (op.kind != OP_CONV && op.kind != OP_CONV0) continue;
         if (op.conv == i) {
             o->tile_h = op.cfg.TH; o->tile_w = op.cfg.TW; o->waves_n = op.cfg.WN; o->nrep = op.cfg.NREP;
-            o->lds_bytes = (int32_t)op.cfg.lds; o->persistent = op.cfg.pk;   // 1: conv3_pk, 2: conv1_pk
+            o->lds_bytes = (int32_t)op.cfg.lds; o->persistent = op.cfg.pk;   // 1: conv3_pk, 2: conv1_pk, 3: bneck_pk
+        } else if (op.pair == i) {      // second 3x3 of a fused Bottleneck: runs inside the first one's kernel (bneck_pk)
+            o->tile_h = op.cfg.TH; o->tile_w = op.cfg.TW; o->waves_n = 1; o->nrep = op.cfg.NREP; o->lds_bytes = 0; o->fused = 1;
+            o->persistent = 1;
         } else if (op.fold == i) {      // ConvTranspose folded into the following 3x3 (convfold_kernel): never materialised
-            o->tile_h = op.cfg.TH; o->tile_w = op.cfg.TW; o->waves_n = 4; o->nrep = op.cfg.NREP; o->lds_bytes = 0;   // `fused` stays 0: that flag means "runs inside the PREVIOUS row's kernel"
+            o->tile_h = op.cfg.TH; o->tile_w = op.cfg.TW; o->persistent = op.cfg.pk; o->waves_n = 4; o->nrep = op.cfg.NREP; o->lds_bytes = 0;   // `fused` stays 0: that flag means "runs inside the PREVIOUS row's kernel"
         } else if (op.fused_l1 == i) {  // layer 1 inside the stem's kernel (stem_l1_kernel: 16 x 20 output tiles, 2 n-tiles)
             stem_l1_tile(&o->tile_h, &o->tile_w); o->waves_n = 1; o->nrep = 2; o->lds_bytes = 0; o->fused = 1;
         } else if (op.fused == i) {     // runs inside its producer's kernel, on that kernel's geometry
@@ -277,9 +280,10 @@ static void fill_conv_params(int conv_elem_size, ConvParams& p, const ConvRow& r
         const size_t es = conv_elem_size;
         const size_t ib = (size_t)B * r.h_in * r.w_in * in_ld * es, ob = (size_t)B * p.Hout * p.Wout * out_ld * (out_f32 ? 4 : es);
         const size_t rb = res ? (size_t)B * p.Hout * p.Wout * res_ld * es : 0;
-        p.pk = (ib < 0x80000000ull && ob < 0x80000000ull && rb < 0x80000000ull) ? 1 : 0;   // 2^31 marks out-of-range lanes
+        p.pk = (ib < 0x80000000ull && ob < 0x80000000ull && rb < 0x80000000ull) ? g.pk : 0;   // 2^31 marks out-of-range lanes
         p.in_bytes = (unsigned)ib; p.out_bytes = (unsigned)ob; p.res_bytes = (unsigned)rb;
         p.pk_tiles = B * p.tiles_y * p.tiles_x;
+        p.pk_depth = g.pk_depth;
         const int gy = g.ntiles_n / (g.WN * g.NREP);
         int G = std::min(p.pk_tiles, std::max(1, 256 * g.pk_wgpc / gy));
         if (const char* cap = getenv("VTI_PK_MAX_WGS")) G = std::max(1, std::min(G, atoi(cap)));   // tests: force many tiles per workgroup
@@ -305,7 +309,7 @@ int32_t vti_forward(vti_ctx* c, const uint8_t* input, int32_t B, int32_t swap_rb
             const bool cv = op.kind == OP_CONV || op.kind == OP_CONV0;
             fprintf(stderr, "[op %2d] lane %d %s%s%s\n", i++, op.lane,
                     cv ? P.convs[op.conv].name.c_str() : op.kind == OP_POOL ? "sppf_pool" : op.kind == OP_UP2 ? "upsample2x" : "decode",
-                    cv && op.fused_l1 >= 0 ? (" + " + P.convs[op.fused_l1].name).c_str() : cv && op.fold >= 0 ? (" (folded: " + P.convs[op.fold].name + ")").c_str() : "",
+                    cv && op.fused_l1 >= 0 ? (" + " + P.convs[op.fused_l1].name).c_str() : cv && op.fold >= 0 ? (" (folded: " + P.convs[op.fold].name + ")").c_str() : cv && op.pair >= 0 ? (" + " + P.convs[op.pair].name).c_str() : "",
                     cv && op.fused >= 0 ? (" + " + P.convs[op.fused].name).c_str() : "");
         }
     }
@@ -392,7 +396,18 @@ int32_t vti_forward(vti_ctx* c, const uint8_t* input, int32_t B, int32_t swap_rb
                 q.act2 = P.convs[op.fused].kind == 0; q.out2_f32 = op.out2_f32 ? 1 : 0;
                 q.scalar_store2 = (g.gemm_n2 % 4 || o2.C % 4 || op.out2.coff % 4) ? 1 : 0;
                 q.out2_bstride = 4 * q.Hout * q.Wout;
-                VTI_HIP(c, launch_convfold(dt, q, g.lds, st), r.name.c_str());
+                if (g.pk) {             // persistent schedule: composed weights resident in LDS, tiles walked per XCD
+                    q.pk = 1; q.pk_depth = g.pk_depth; q.in_bytes = (unsigned)((size_t)B * q.Hin * q.Win * q.in_ld * P.esize);
+                    q.pk_tiles = B * q.tiles_y * q.tiles_x;
+                    int G = std::min(q.pk_tiles, 256);
+                    if (const char* cap = getenv("VTI_PK_MAX_WGS")) G = std::max(1, std::min(G, atoi(cap)));
+                    q.pk_xcd = G >= 8 ? 1 : 0;
+                    if (q.pk_xcd) G &= ~7;
+                    q.pk_wgs = G;
+                    VTI_HIP(c, launch_conv_pk_fold(dt, q, g.lds, st), r.name.c_str());
+                } else {
+                    VTI_HIP(c, launch_convfold(dt, q, g.lds, st), r.name.c_str());
+                }
                 break;
             }
             ConvParams p;
@@ -419,6 +434,11 @@ int32_t vti_forward(vti_ctx* c, const uint8_t* input, int32_t B, int32_t swap_rb
                     p.dfl_stride = (float)op.dfl_stride;
                     p.scalar_store2 = (g.gemm_n2 % 4 || no % 4 || op.pred_cbase % 4) ? 1 : 0;
                 }
+            }
+            if (op.pair >= 0) {         // fused Bottleneck: second conv's weights; p.out / p.res already are the second conv's views
+                p.w2 = (const char*)c->d_wpk + g.wpk_off2;
+                p.bias2 = c->d_bias + g.bias_off2;
+                if (p.pk != 3) return fail(c, VTI_ERR_UNSUPPORTED, "fused bottleneck needs the persistent kernel (tensor too large?)");
             }
             if (op.up_C > 0) {
                 const Buf& ub = P.bufs[op.up_src.buf];

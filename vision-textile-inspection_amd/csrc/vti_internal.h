@@ -59,7 +59,7 @@ struct ConvCfg {         // launch geometry chosen at plan time
     size_t wpk_off2 = 0, bias_off2 = 0;
     size_t wpk_off3 = 0, bias_off3 = 0;   // stem_l1_kernel with a fused 1x1 third conv: that conv's stage-2 pack (offsets 2 = layer 1)
     // persistent LDS-DMA kernel (conv_pk.hip): TW = 20, TH = 4 * M-waves; wgpc = co-resident workgroups per CU
-    int pk = 0, pk_wgpc = 1;         // pk: 1 = conv3_pk, 2 = conv1_pk (TH = compute waves along M, TW = 80)
+    int pk = 0, pk_wgpc = 1;         // pk: 1 = conv3_pk, 2 = conv1_pk (TH = compute waves along M, TW = 80), 3 = bneck_pk (fused 3x3 -> 3x3 pair)
     int pk_depth = 2, pk_wstat = 0;  // conv1_pk: stage-ring depth, weights stationary in LDS
 };
 
@@ -70,6 +70,7 @@ struct Op {
     bool has_res = false;
     bool out_f32 = false;
     int fused = -1;      // conv index of a 1x1 conv fused into this op's epilogue (its own op is dropped)
+    int pair = -1;       // conv index of the SECOND 3x3 of a fused C2f Bottleneck (bneck_pk): this op is the first; out/res are the second's
     int fold = -1;       // conv index of a ConvTranspose2d(2,2) FOLDED into this 3x3 conv (convfold_kernel): `in` is then the deconv's input
     int fused_l1 = -1;   // OP_CONV0 only: conv index of layer 1 computed by the same kernel (stem_l1_kernel); out/out2 = layer 1's view
     int pred_mode = 0, pred_cbase = 0, pred_a0 = 0;   // fused stage writes into pred instead of a head buffer (1 raw, 2 sigmoid, 3 DFL boxes)
@@ -146,17 +147,25 @@ bool convfold_supported(int c_in, int c_mid, int c_out, int ntiles2);
 void pack_conv_fold(int dtype, const ConvRow& rU, const ConvRow& rV, const ConvCfg& c, const float* wU, const float* bU,
                     const float* wV, const float* bV, uint8_t* dst_w, float* dst_b);
 size_t packed_fold_bytes(const ConvCfg& c);
+hipError_t launch_conv_pk_fold(int dtype, const ConvParams& p, size_t lds_bytes, hipStream_t st);   // the same on the persistent schedule
+size_t conv_pk_fold_lds_bytes(int nchunks, int depth);
+int conv_pk_fold_depth(int nchunks);
 void pack_conv_l1pairs(int dtype, const ConvRow& r1, const float* w, const float* b, uint8_t* dst_w, float* dst_b);
 size_t packed_l1pairs_bytes(int dtype);
 // conv_pk.hip: persistent 3x3/s1 kernel
 hipError_t launch_conv_pk(int dtype, int nrep, const ConvParams& p, size_t lds_bytes, hipStream_t st);
 size_t conv_pk_lds_bytes(int TH, int WN, int NREP, int nchunks);
+size_t conv_pk_lds_bytes(int TH, int WN, int NREP, int nchunks, int depth);
+int conv_pk_depth(int TH, int WN, int NREP, int nchunks);
 bool conv_pk_fits(int TH, int WN, int NREP, int nchunks);
 bool conv_pk_instantiated(int nrep, int wn);
 hipError_t launch_conv1_pk(int dtype, int nrep, const ConvParams& p, size_t lds_bytes, hipStream_t st);
 size_t conv1_pk_lds_bytes(int nwm, int WN, int NREP, int nchunks, int depth, int wstat);
 bool conv1_pk_fits(int nwm, int WN, int NREP, int nchunks, int depth, int wstat);
 bool conv1_pk_instantiated(int nrep, int wn);
+hipError_t launch_bneck_pk(int dtype, int nrep, const ConvParams& p, size_t lds_bytes, hipStream_t st);
+size_t bneck_pk_lds_bytes(int TH, int NREP);
+bool bneck_pk_fits(int TH, int NREP);
 
 struct PoolParams { const void* in; void* out; int B, H, W, C, ld, in_coff, out_coff; };
 hipError_t launch_sppf_pool(int dtype, const PoolParams& p, hipStream_t st);

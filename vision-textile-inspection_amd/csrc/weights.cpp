@@ -221,6 +221,9 @@ std::string pack_weights(const Plan& plan, const void* blob, size_t nbytes, std:
             if (op.fused_l1 >= 0) l1_host[op.fused_l1] = &op;
         }
 
+    std::vector<const Op*> pair_host(plan.convs.size(), nullptr);      // second 3x3 of a fused Bottleneck -> the op of the first
+    for (const Op& op : plan.ops)
+        if (op.kind == OP_CONV && op.pair >= 0) pair_host[op.pair] = &op;
     std::vector<const Op*> fold_host(plan.convs.size(), nullptr);      // deconv index -> the 3x3 op it is folded into
     for (const Op& op : plan.ops)
         if ((op.kind == OP_CONV) && op.fold >= 0) fold_host[op.fold] = &op;
@@ -244,6 +247,11 @@ std::string pack_weights(const Plan& plan, const void* blob, size_t nbytes, std:
         memcpy(w.data(), p + off, 4 * nw); off += 4 * nw;
         memcpy(b.data(), p + off, 4 * (size_t)r.c2); off += 4 * (size_t)r.c2;
 
+        if (pair_host[i]) {
+            const ConvCfg& hc = pair_host[i]->cfg;
+            pack_conv(plan.desc.dtype, r, false, hc, w.data(), b.data(), wpk.data() + hc.wpk_off2, bias.data() + hc.bias_off2);
+            continue;
+        }
         if (fold_host[i]) { fold_w = w; fold_b = b; continue; }          // packed together with the 3x3 that follows
         if (op_of[i] && op_of[i]->fold >= 0) {
             const Op& op = *op_of[i];
