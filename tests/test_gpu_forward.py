@@ -100,9 +100,16 @@ def test_batch_invariance_and_flags():
     p2, q2 = eng.forward(x)
     p1, q1 = eng.forward(x[1:2].contiguous())
     assert torch.equal(p2[1], p1[0]) and torch.equal(q2[1], q1[0])
+    # swap_rb=False == pre-flipping the channels.  Equal in exact arithmetic; the stem's banded weights put the flipped channels at
+    # other K positions of the MFMA, so the fp32 sums may round differently (a few fp16 ulps after 76 layers): close, not bit-equal,
+    # and each path matches the oracle run with the same flag
     pa, _ = eng.forward(x, swap_rb=False)
     pb, _ = eng.forward(x.flip(-1).contiguous(), swap_rb=True)
-    assert torch.equal(pa, pb)
+    assert (pa[:, 4:84] - pb[:, 4:84]).abs().max() < 2e-2 and (pa[:, :4] - pb[:, :4]).abs().max() < 4.0
+    _, om, _ = engine_and_oracle("n", 80, 640, 640, 2, "fp16")
+    oa, _ = om.forward_u8(fr, swap_rb=False)
+    assert (pa[:, 4:84].cpu() - oa[:, 4:84]).abs().max() < 2e-2
+    assert not torch.allclose(pa[:, 4:84], p2[:, 4:84], atol=1e-3)         # and the flag does something
 
 
 def test_full_size_batch_properties():

@@ -498,11 +498,18 @@ __global__ __launch_bounds__(256) void stem_kernel(const ConvParams p) {
 // w0 / bias0 = the stem's packed weights / bias; w2 / bias2 / out2 (non-null) = the fused third conv.
 constexpr int SL_TH = 8, SL_TW = 40;       // 35 patch rows of 489 B: the u8 reads are DRAM-bound on segment length (20-wide tiles: 252 B, 2x slower staging)
 constexpr int SL_SH = 2 * SL_TH + 1, SL_SW = 2 * SL_TW + 1, SL_NSP = SL_SH * SL_SW;       // stem pixels per tile
-constexpr int SL_RH = 4 * SL_TH + 3, SL_RWB = (4 * SL_TW + 3) * 3, SL_RWD = (SL_RWB + 6) >> 2, SL_PITCH = SL_RWD * 4;
+constexpr int SL_RH = 4 * SL_TH + 3, SL_RWB = (4 * SL_TW + 3) * 3, SL_RWD = (SL_RWB + 6) >> 2;
+// Row pitch of the converted patch in elements.  The stem reads it as aligned 32-element windows (see phase 2): window J of a row
+// starts at element 24 J, so the last window (J = 20) reaches element 511 and the pitch must cover it with FINITE values (zero
+// filled past the 492 real ones: they meet zero weights); 16-byte aligned rows.  fp16: 520 (1040 B: consecutive stem rows then sit
+// 32 B apart modulo the 256-B bank row, so two rows of one 16-window block do not collide); fp32: 512, what still fits 160 KiB.
+constexpr int sl_pitch(int es) { return es == 2 ? 520 : 512; }
+constexpr int SL_NJ = (SL_SW + 3) / 4, SL_NWIN = SL_SH * SL_NJ;       // 4-pixel windows per stem row / per tile
+static_assert(24 * (SL_NJ - 1) + 32 <= 512 && SL_RWD * 4 <= 512, "stem windows must stay inside a patch row");
 
 size_t stem_l1_lds_bytes(int dtype) {
     const size_t es = dtype == VTI_F16 ? 2 : 4;
-    return (((size_t)SL_RH * SL_PITCH * es + 15) & ~(size_t)15) + (size_t)SL_NSP * 16 * es;
+    return (((size_t)SL_RH * sl_pitch((int)es) * es + 15) & ~(size_t)15) + (size_t)SL_NSP * 16 * es;
 }
 
 template <typename T>
@@ -512,6 +519,7 @@ __global__ __launch_bounds__(256) void stem_l1_kernel(const ConvParams p) {
     constexpr int NCH = 32 / KC;                        // stem K chunks (27 -> 32)
     constexpr int NS1 = sizeof(T) == 2 ? 5 : 9;         // layer-1 K steps
     constexpr bool FAST = sizeof(T) == 2;
+    constexpr int SL_PITCH = sl_pitch(ES);
     constexpr int CP_BYTES = (SL_RH * SL_PITCH * ES + 15) & ~15;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* cp = (T*)smem;                                   // the input patch, already v/255 in T: [row][SL_PITCH]
@@ -526,10 +534,31 @@ __global__ __launch_bounds__(256) void stem_l1_kernel(const ConvParams p) {
     const int sy0 = 2 * oy0 - 1, sx0 = 2 * ox0 - 1;     // stem-map origin of the tile's stem pixels
     const int Hs = (p.Hin - 1) / 2 + 1, Ws = (p.Win - 1) / 2 + 1;       // stem map (k3 s2 p1)
     const int iy0 = 2 * sy0 - 1;
-    const int x0b = (2 * sx0 - 1) * 3, a0 = x0b & ~3, shift = x0b - a0;
+    const int x0b = (2 * sx0 - 1) * 3, a0 = x0b & ~3;           // x0b = 12 ox0 - 9, so x0b - a0 == 3 for every tile (phase 2 relies on it)
     const uint8_t* inb = (const uint8_t*)p.in + (size_t)b * p.Hin * p.Win * 3;
     const int rowbytes = p.Win * 3;
     VTI_STAMP(0);
+    // Every weight fragment of the three convs is fetched NOW (fp16: 48 + 40 + 8 registers), so that the round trips hide under the
+    // patch staging: loaded where they are used, each phase opened with an exposed L2 latency (the stem phase alone spent ~6 k of
+    // its 12 k cycles per workgroup waiting for its 12 fragments).
+    vec wA[4][3][NCH];
+    {
+        const vec* w0 = (const vec*)p.w0 + (size_t)(p.swap_rb ? 1 : 0) * (4 * 3 * NCH * 64);
+#pragma unroll
+        for (int pp = 0; pp < 4; ++pp)
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) wA[pp][kh][c] = w0[(size_t)((pp * 3 + kh) * NCH + c) * 64 + lane];
+    }
+    vec w1all[NS1][2];
+#pragma unroll
+    for (int s1 = 0; s1 < NS1; ++s1)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) w1all[s1][n] = ((const vec*)p.wpk)[((size_t)s1 * 2 + n) * 64 + lane];
+    const f32x4 bias0_4 = *(const f32x4*)(p.bias0 + g * 4);
+    Stage2Regs<T, 2, 2> s2r;
+    if (p.out2) stage2_preload<T, 2, 2>(p, lane, false, s2r);
     // ---- phase 1: u8 -> T(v / 255) while staging.  fp16: v * (1/255) rounds to the same half as v / 255 for all 256 byte
     // values (checked exhaustively), so no table and no division; fp32 divides (what torch's `im.float() / 255` does).
     {   // wave w stages rows w, w+4, ...; a row is SL_RWD dwords = RC lane-chunks: all row arithmetic is scalar, the column test
@@ -607,56 +636,54 @@ __global__ __launch_bounds__(256) void stem_l1_kernel(const ConvParams p) {
             }
         }
     }
+    // elements [4 SL_RWD, SL_PITCH) of every row: read by the last stem window of the row, must be finite (zero weights meet them)
+    for (int i = tid; i < SL_RH * ((SL_PITCH - 4 * SL_RWD) / 4); i += 256) {
+        const int ry = i / ((SL_PITCH - 4 * SL_RWD) / 4), c4 = i - ry * ((SL_PITCH - 4 * SL_RWD) / 4);
+        T* o = cp + (size_t)ry * SL_PITCH + 4 * SL_RWD + 4 * c4;
+        o[0] = (T)0; o[1] = (T)0; o[2] = (T)0; o[3] = (T)0;
+    }
     __syncthreads();
     VTI_STAMP(1);
-    // ---- phase 2: stem (two m-tiles per iteration so their LDS gathers overlap)
+    // ---- phase 2: stem as a Toeplitz GEMM -- no gathers.  Output pixel sx of a stem row reads patch elements 6 sx + 3 .. 6 sx + 11
+    // of input rows 2 sy + kh (the tile's byte offset inside its first dword is always 3: 12 ox0 - 9), so the FOUR pixels 4J .. 4J+3
+    // read inside the ALIGNED 32-element window [24 J, 24 J + 32) of each of the three rows.  One MFMA column = one window (16 windows
+    // of consecutive (row, J) per block), K = the window's 32 elements (one aligned ds_read_b128 per lane and input row), and the
+    // weights are expanded on the host into 4 x 3 banded fragments W'[p][kh][co][k] = w[co][kh][k - 6 p - 3] (weights.cpp:
+    // pack_stem_toeplitz; both channel orders, selected by swap_rb).  12 MFMAs per 64 pixels instead of 4, but the 8 scalar LDS
+    // gathers + packing per lane and m-tile that bounded this phase (15 k of ~30 k cycles per workgroup) are gone.
     {
-        int off[NCH][VEC];
-        vec w[NCH];
+        const f32x4 bias4 = bias0_4;
+        constexpr int NBLK = (SL_NWIN + 15) / 16;
+        for (int blk = wave; blk < NBLK; blk += 4) {
+            const int wi = blk * 16 + (lane & 15);
+            const bool wvalid = wi < SL_NWIN;
+            const int wc = wvalid ? wi : SL_NWIN - 1;
+            // rows fastest: the 16 windows of a block are 16 different stem rows, whose output pixels sy * 81 + 4 J + p fall on 4
+            // different bank groups of the [pixel][32 B] tile (consecutive J of one row would all hit the same one: 16-way conflict)
+            const int J = wc / SL_SH, sy = wc - J * SL_SH;
+            const T* base = cp + (size_t)(2 * sy) * SL_PITCH + 24 * J + g * VEC;
+            vec x[3][NCH];
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) {
+            for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) {
-                const int k = c * KC + g * VEC + j;
-                const int tap = k / 3, chn = k - tap * 3;
-                const int kh = tap / 3, kw = tap - kh * 3;
-                off[c][j] = k < 27 ? kh * SL_PITCH + kw * 3 + (p.swap_rb ? 2 - chn : chn) : -1;
+                for (int c = 0; c < NCH; ++c) x[kh][c] = *(const vec*)(base + kh * SL_PITCH + c * KC);
+            f32x4 acc[4];
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp) {
+                acc[pp] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) acc[pp] = mma(wA[pp][kh][c], x[kh][c], acc[pp]);
             }
-            w[c] = ((const vec*)p.w0)[(size_t)c * 64 + lane];          // one n-tile (16 stem channels)
-        }
-        const f32x4 bias4 = *(const f32x4*)(p.bias0 + g * 4);
-        constexpr int NMT = (SL_NSP + 15) / 16;
-        constexpr int UN = 4;
-        for (int mt0 = wave; mt0 < NMT; mt0 += 4 * UN) {
-            f32x4 acc[UN];
-            int q[UN];
-            bool inside[UN];
-            vec x[UN][NCH];
+            const bool row_in = (unsigned)(sy0 + sy) < (unsigned)Hs;
 #pragma unroll
-            for (int u = 0; u < UN; ++u) {
-                const int mt = mt0 + 4 * u;
-                q[u] = mt * 16 + (lane & 15);
-                const int qc = q[u] < SL_NSP ? q[u] : SL_NSP - 1;
-                const int sy = qc / SL_SW, sx = qc - sy * SL_SW;
-                const int rbase = (2 * sy) * SL_PITCH + (2 * sx) * 3 + shift;
-                inside[u] = (unsigned)(sy0 + sy) < (unsigned)Hs && (unsigned)(sx0 + sx) < (unsigned)Ws;
-#pragma unroll
-                for (int c = 0; c < NCH; ++c)
-#pragma unroll
-                    for (int j = 0; j < VEC; ++j) x[u][c][j] = off[c][j] >= 0 ? cp[rbase + off[c][j]] : (T)0;
-            }
-#pragma unroll
-            for (int u = 0; u < UN; ++u) {
-                acc[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int c = 0; c < NCH; ++c) acc[u] = mma(w[c], x[u][c], acc[u]);
-            }
-#pragma unroll
-            for (int u = 0; u < UN; ++u) {
-                f32x4 v = silu4<FAST>(acc[u] + bias4);
-                if (!inside[u]) v = (f32x4){0.f, 0.f, 0.f, 0.f};           // layer 1's zero padding
-                if (q[u] < SL_NSP) {
-                    T* o = (T*)(sout + ((size_t)q[u] * 16 + g * 4) * ES);
+            for (int pp = 0; pp < 4; ++pp) {
+                const int sx = 4 * J + pp;
+                f32x4 v = silu4<FAST>(acc[pp] + bias4);
+                if (!(row_in && (unsigned)(sx0 + sx) < (unsigned)Ws)) v = (f32x4){0.f, 0.f, 0.f, 0.f};     // layer 1's zero padding
+                if (wvalid && sx < SL_SW) {
+                    T* o = (T*)(sout + ((size_t)(sy * SL_SW + sx) * 16 + g * 4) * ES);
                     if constexpr (sizeof(T) == 2) {
                         half4 hv;
 #pragma unroll
@@ -692,7 +719,7 @@ __global__ __launch_bounds__(256) void stem_l1_kernel(const ConvParams p) {
         const int toff = ((tc / 3) * SL_SW + (tc % 3)) * 16 * ES + (sizeof(T) == 2 ? (g & 1) * 8 : g * 4) * ES;
         vec w1[2];
 #pragma unroll
-        for (int n = 0; n < 2; ++n) w1[n] = ((const vec*)p.wpk)[((size_t)s * 2 + n) * 64 + lane];
+        for (int n = 0; n < 2; ++n) w1[n] = w1all[s][n];
 #pragma unroll
         for (int m = 0; m < MREP; ++m) {
             const vec x = *(const vec*)(sout + sbase[m] + toff);
@@ -702,7 +729,7 @@ __global__ __launch_bounds__(256) void stem_l1_kernel(const ConvParams p) {
     }
     VTI_STAMP(3);
     // ---- phase 4: layer 1's epilogue, or (model.2.cv1 fused) the 1x1 conv on layer 1's register tile
-    if (p.out2) conv_stage2<T, 2, 2>(p, acc, pvalid, opy, opx, b, lane);
+    if (p.out2) conv_stage2<T, 2, 2, false, true>(p, acc, pvalid, opy, opx, b, lane, &s2r);
     else conv_epilogue<T, 2>(p, acc, pvalid, opy, opx, b, 0, 0, lane);
     VTI_STAMP(12);
 }

@@ -249,7 +249,9 @@ __global__ __launch_bounds__(512) void conv3_pk(const ConvParams p) {
                 const char* sx = smem + cur * stage_bytes;
                 const char* sw = smem + wbuf_off + (stream_w ? cur : c) * WCHUNK + wn * (NREP * TAPS * 1024) + lane * 16;
                 constexpr int NSTEP = TAPS * MREP;
-                constexpr int XD = 3, WD = 2;
+                // pixel fragments in flight: a step is NREP MFMAs (16 cycles each), an LDS read takes ~100+ cycles with 8 waves on
+                // the CU, so small register tiles need a deeper queue to keep the matrix pipe fed
+                constexpr int XD = NREP >= 4 ? 3 : NREP == 3 ? 4 : NREP == 2 ? 6 : 8, WD = 2;
                 vec xq[XD];
                 vec wq[WD][NREP];
                 auto ldx = [&](int s_) -> vec {
@@ -262,8 +264,8 @@ __global__ __launch_bounds__(512) void conv3_pk(const ConvParams p) {
                     for (int n = 0; n < NREP; ++n) w[n] = *(const vec*)(sw + (n * TAPS + tp) * 1024);
                 };
                 ldw(0, wq[0]);
-                xq[0] = ldx(0);
-                xq[1] = ldx(1);
+#pragma unroll
+                for (int i = 0; i < XD - 1; ++i) xq[i] = ldx(i);
 #pragma unroll
                 for (int s_ = 0; s_ < NSTEP; ++s_) {
                     const int tp = s_ / MREP, mm = s_ % MREP;
@@ -767,8 +769,20 @@ hipError_t launch_conv_pk(int dtype, int nrep, const ConvParams& p, size_t lds_b
 // Two workgroup barriers per tile.  ConvParams: wpk/bias = conv 1, w2/bias2 = conv 2; res must be the input view when has_res.
 constexpr int BN_MREP1 = 7;
 
-size_t bneck_pk_lds_bytes(int TH, int NREP) {
-    return 2 * (size_t)(TH + 4) * PK_PWP * 64 + (size_t)(TH + 2) * PK_PWP * 64 + 2 * (size_t)NREP * 9 * 1024 + 2 * (size_t)NREP * 64;
+size_t bneck_pk_lds_bytes(int TH, int NREP, int depth) {
+    return depth * (size_t)(TH + 4) * PK_PWP * 64 + (size_t)(TH + 2) * PK_PWP * 64 + 2 * (size_t)NREP * 9 * 1024 + 2 * (size_t)NREP * 64;
+}
+size_t bneck_pk_lds_bytes(int TH, int NREP) { return bneck_pk_lds_bytes(TH, NREP, 2); }
+// patch stages: as many (<= 4) as fit -- these layers are HBM-bound and one 15-30 KB patch in flight per CU is ~1/3 of what
+// Little's law asks for at ~2 us of loaded latency
+int bneck_pk_depth(int TH, int NREP) {
+    const char* cap = getenv("VTI_PK_DEPTH");
+    const int maxd = cap ? std::max(2, std::min(4, atoi(cap))) : 4;
+    const int nwm = TH / PK_ROWS;
+    const int per_step = ((TH + 4) * PK_PWP / 16 + nwm - 1) / nwm;
+    int d = 2;
+    while (d < maxd && bneck_pk_lds_bytes(TH, NREP, d + 1) <= 160 * 1024 && per_step * (d - 1) <= 63) ++d;
+    return d;
 }
 bool bneck_pk_fits(int TH, int NREP) {
     if (TH % PK_ROWS || TH < 8 || TH > 16 || NREP < 1 || NREP > 2) return false;
@@ -792,7 +806,8 @@ __global__ __launch_bounds__(512) void bneck_pk(const ConvParams p) {
     const int nwm = p.TH / PK_ROWS;                         // compute waves; as many loader waves
     const int PH = p.TH + 4, R1H = p.TH + 2;
     const int stage_bytes = PH * PK_PWP * 64;
-    const int timg_off = 2 * stage_bytes;
+    const int D = p.pk_depth;                               // patch stages
+    const int timg_off = D * stage_bytes;
     const int w1_off = timg_off + R1H * PK_PWP * 64;
     const int w2_off = w1_off + NREP * TAPS * 1024;
     const int bias_off = w2_off + NREP * TAPS * 1024;
@@ -820,6 +835,7 @@ __global__ __launch_bounds__(512) void bneck_pk(const ConvParams p) {
         const int ty = r % p.tiles_y;
         b = r / p.tiles_y; oy0 = ty * p.TH; ox0 = tx * PK_TW;
     };
+    const int ntiles_mine = (tend - t + tstride - 1) / tstride;
 
     if (wave >= nwm) {
         // =================== loader waves ===================
@@ -854,16 +870,17 @@ __global__ __launch_bounds__(512) void bneck_pk(const ConvParams p) {
             dma16(rsW1, (unsigned)lane * 16u, (unsigned)(f * 1024), lds0 + w1_off + f * 1024);
             dma16(rsW2, (unsigned)lane * 16u, (unsigned)(f * 1024), lds0 + w2_off + f * 1024);
         }
-        issue_patch(t, 0);
-        int step = 0;
-        while (true) {
-            wait_vm<0>();
-            __builtin_amdgcn_s_barrier();                   // A: patch(step) has landed; every compute wave left the other stage and the T image
-            const int tn = t + tstride;
-            if (tn < tend) issue_patch(tn, (step + 1) & 1);
+        int per_step = 0;
+#pragma unroll
+        for (int u = 0; u < PK_MAXD; ++u) per_step += (lw + u * nld < ndma) ? 1 : 0;
+        // the loaders run D - 1 tiles ahead; before barrier A(s) they wait (counted) for everything up to patch(s)
+        const int ahead = min(D - 1, ntiles_mine);
+        for (int s = 0; s < ahead; ++s) issue_patch(t + s * tstride, s % D);
+        for (int s = 0; s < ntiles_mine; ++s) {
+            WaitVm<63>::go(min(63, min(D - 2, ntiles_mine - 1 - s) * per_step));
+            __builtin_amdgcn_s_barrier();                   // A: patch(s) has landed; every compute wave left stage (s - 1) % D and the T image
+            if (s + D - 1 < ntiles_mine) issue_patch(t + (s + D - 1) * tstride, (s + D - 1) % D);
             __builtin_amdgcn_s_barrier();                   // B
-            if (tn >= tend) break;
-            t = tn; ++step;
         }
         return;
     }
@@ -917,12 +934,15 @@ __global__ __launch_bounds__(512) void bneck_pk(const ConvParams p) {
     }
     const bool has_res = __builtin_amdgcn_readfirstlane(p.has_res) != 0;
     int step = 0;
+    VTI_STAMP(0);
     while (true) {
         int b, oy0, ox0;
         tile_coords(t, b, oy0, ox0);
-        const char* sx = smem + (step & 1) * stage_bytes;
+        const char* sx = smem + (step % D) * stage_bytes;
+        if (step == 2) VTI_STAMP(1);
         __builtin_amdgcn_s_barrier();                       // A
         asm volatile("" ::: "memory");
+        if (step == 2) VTI_STAMP(2);
         // ---- phase 1: conv 1 on the grown tile
         {
             f32x4 acc[BN_MREP1][NREP];
@@ -932,7 +952,8 @@ __global__ __launch_bounds__(512) void bneck_pk(const ConvParams p) {
                 for (int n = 0; n < NREP; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
             const char* sw = smem + w1_off + lane * 16;
             constexpr int NSTEP = TAPS * BN_MREP1;
-            vec xq[3];
+            constexpr int XD = NREP == 2 ? 6 : 8;           // pixel fragments in flight (a step is only NREP MFMAs long)
+            vec xq[XD];
             vec wq[2][NREP];
             auto ldx = [&](int s_) -> vec {
                 const int tp = s_ / BN_MREP1, mm = s_ % BN_MREP1;
@@ -943,18 +964,19 @@ __global__ __launch_bounds__(512) void bneck_pk(const ConvParams p) {
                 for (int n = 0; n < NREP; ++n) w[n] = *(const vec*)(sw + (n * TAPS + tp) * 1024);
             };
             ldw(0, wq[0]);
-            xq[0] = ldx(0);
-            xq[1] = ldx(1);
+#pragma unroll
+            for (int i = 0; i < XD - 1; ++i) xq[i] = ldx(i);
 #pragma unroll
             for (int s_ = 0; s_ < NSTEP; ++s_) {
                 const int tp = s_ / BN_MREP1, mm = s_ % BN_MREP1;
-                if (s_ + 2 < NSTEP) xq[(s_ + 2) % 3] = ldx(s_ + 2);
+                if (s_ + XD - 1 < NSTEP) xq[(s_ + XD - 1) % XD] = ldx(s_ + XD - 1);
                 if (mm == 0 && tp + 1 < TAPS) ldw(tp + 1, wq[(tp + 1) % 2]);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int n = 0; n < NREP; ++n) acc[mm][n] = mma(wq[tp % 2][n], xq[s_ % 3], acc[mm][n]);
+                for (int n = 0; n < NREP; ++n) acc[mm][n] = mma(wq[tp % 2][n], xq[s_ % XD], acc[mm][n]);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if (step == 2) VTI_STAMP(3);
             // bias + SiLU, rounded to T, into the T image; a pixel outside the feature map is conv 2's zero padding
 #pragma unroll
             for (int m = 0; m < BN_MREP1; ++m) {
@@ -984,8 +1006,10 @@ __global__ __launch_bounds__(512) void bneck_pk(const ConvParams p) {
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's T-image writes have been performed (a raw s_barrier does not wait)
+        if (step == 2) VTI_STAMP(4);
         __builtin_amdgcn_s_barrier();                       // B: the T image is complete
         asm volatile("" ::: "memory");
+        if (step == 2) VTI_STAMP(5);
         // ---- phase 2: conv 2 on the tile, from the T image
         {
             f32x4 acc[MREP][NREP];
@@ -995,7 +1019,8 @@ __global__ __launch_bounds__(512) void bneck_pk(const ConvParams p) {
                 for (int n = 0; n < NREP; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
             const char* sw = smem + w2_off + lane * 16;
             constexpr int NSTEP = TAPS * MREP;
-            vec xq[3];
+            constexpr int XD = NREP == 2 ? 6 : 8;
+            vec xq[XD];
             vec wq[2][NREP];
             auto ldx = [&](int s_) -> vec {
                 const int tp = s_ / MREP, mm = s_ % MREP;
@@ -1006,18 +1031,19 @@ __global__ __launch_bounds__(512) void bneck_pk(const ConvParams p) {
                 for (int n = 0; n < NREP; ++n) w[n] = *(const vec*)(sw + (n * TAPS + tp) * 1024);
             };
             ldw(0, wq[0]);
-            xq[0] = ldx(0);
-            xq[1] = ldx(1);
+#pragma unroll
+            for (int i = 0; i < XD - 1; ++i) xq[i] = ldx(i);
 #pragma unroll
             for (int s_ = 0; s_ < NSTEP; ++s_) {
                 const int tp = s_ / MREP, mm = s_ % MREP;
-                if (s_ + 2 < NSTEP) xq[(s_ + 2) % 3] = ldx(s_ + 2);
+                if (s_ + XD - 1 < NSTEP) xq[(s_ + XD - 1) % XD] = ldx(s_ + XD - 1);
                 if (mm == 0 && tp + 1 < TAPS) ldw(tp + 1, wq[(tp + 1) % 2]);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int n = 0; n < NREP; ++n) acc[mm][n] = mma(wq[tp % 2][n], xq[s_ % 3], acc[mm][n]);
+                for (int n = 0; n < NREP; ++n) acc[mm][n] = mma(wq[tp % 2][n], xq[s_ % XD], acc[mm][n]);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if (step == 2) VTI_STAMP(6);
 #pragma unroll
             for (int m = 0; m < MREP; ++m) {
                 const int gy = oy0 + ry[m], gx = ox0 + rx[m];
@@ -1056,10 +1082,12 @@ __global__ __launch_bounds__(512) void bneck_pk(const ConvParams p) {
                 }
             }
         }
+        if (step == 2) VTI_STAMP(7);
         const int tn = t + tstride;
         if (tn >= tend) break;
         t = tn; ++step;
     }
+    VTI_STAMP(12);
 }
 
 template <typename T, int NREP>
@@ -1083,7 +1111,7 @@ hipError_t launch_bneck_pk(int dtype, int nrep, const ConvParams& p, size_t lds_
     if ((size_t)p.in_bytes >= 0x80000000u || (size_t)p.out_bytes >= 0x80000000u) return hipErrorInvalidValue;
     if (p.has_res && (p.res != p.in || p.res_ld != p.in_ld || p.res_coff != p.in_coff)) return hipErrorInvalidValue;   // shortcut = the input
     if ((p.out_ld | p.out_coff) & (dtype == VTI_F16 ? 7 : 3)) return hipErrorInvalidValue;                              // 16-byte stores
-    if (lds_bytes < bneck_pk_lds_bytes(p.TH, nrep)) return hipErrorInvalidValue;
+    if (p.pk_depth < 2 || p.pk_depth > 4 || lds_bytes < bneck_pk_lds_bytes(p.TH, nrep, p.pk_depth) || lds_bytes > 160 * 1024) return hipErrorInvalidValue;
     if (p.pk_tiles == 0) return hipSuccess;
     const int threads = 2 * (p.TH / PK_ROWS) * 64;
     dim3 grid((unsigned)p.pk_wgs, 1);

@@ -608,7 +608,8 @@ std::string Plan::build(const vti_desc& d) {
             op.cfg.TH = tiles16 >= 256 ? 16 : 8; op.cfg.TW = 20; op.cfg.WN = 1; op.cfg.NREP = r.c2 / 16;
             op.cfg.nchunks = (r.c1 + KC - 1) / KC; op.cfg.gemm_n = r.c2; op.cfg.ntiles_n = r.c2 / 16;
             op.cfg.pk = 3; op.cfg.pk_wgpc = 1;
-            op.cfg.lds = bneck_pk_lds_bytes(op.cfg.TH, op.cfg.NREP);
+            op.cfg.pk_depth = bneck_pk_depth(op.cfg.TH, op.cfg.NREP);
+            op.cfg.lds = bneck_pk_lds_bytes(op.cfg.TH, op.cfg.NREP, op.cfg.pk_depth);
             if (!bneck_pk_fits(op.cfg.TH, op.cfg.NREP) || op.cfg.nchunks != 1) return "no launch configuration for the fused bottleneck " + r.name;
         }
         else if (op.fold >= 0) {         // convfold_kernel: 4 x 20 low-resolution pixels per workgroup, wave = output phase, 4 n-tiles each
@@ -635,6 +636,7 @@ std::string Plan::build(const vti_desc& d) {
         op.cfg.wpk_off = woff;
         op.cfg.bias_off = boff;
         if (op.fold >= 0) { woff += packed_fold_bytes(op.cfg); boff += (size_t)9 * r.c2; }      // bias: [3 x 3 border classes][Cout]
+        else if (op.kind == OP_CONV0 && op.fused_l1 >= 0) { woff += packed_stem_toeplitz_bytes(d.dtype); boff += 16; }
         else { woff += packed_conv_bytes(r, op.kind == OP_CONV0, op.cfg); boff += (size_t)op.cfg.ntiles_n * 16; }
         if (op.pair >= 0) {         // second conv of the pair: the same packing, its own slot
             op.cfg.wpk_off2 = woff; op.cfg.bias_off2 = boff;

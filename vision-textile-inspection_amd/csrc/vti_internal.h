@@ -140,6 +140,8 @@ bool conv_cfg_fits(int ks, int stride, int mode, int TH, int TW, int WN, int NRE
 hipError_t launch_stem_l1(int dtype, const ConvParams& p, hipStream_t st);
 size_t stem_l1_lds_bytes(int dtype);
 void stem_l1_tile(int* th, int* tw);
+void pack_stem_toeplitz(int dtype, const ConvRow& r0, const float* w, const float* b, uint8_t* dst_w, float* dst_b);
+size_t packed_stem_toeplitz_bytes(int dtype);
 // ConvTranspose2d(C,C,2,2) folded into the following 3x3 conv (+ its fused 1x1): four 2x2 convs on the low-resolution map
 hipError_t launch_convfold(int dtype, const ConvParams& p, size_t lds_bytes, hipStream_t st);
 size_t convfold_lds_bytes(int TH, int TW);
@@ -165,6 +167,8 @@ bool conv1_pk_fits(int nwm, int WN, int NREP, int nchunks, int depth, int wstat)
 bool conv1_pk_instantiated(int nrep, int wn);
 hipError_t launch_bneck_pk(int dtype, int nrep, const ConvParams& p, size_t lds_bytes, hipStream_t st);
 size_t bneck_pk_lds_bytes(int TH, int NREP);
+size_t bneck_pk_lds_bytes(int TH, int NREP, int depth);
+int bneck_pk_depth(int TH, int NREP);
 bool bneck_pk_fits(int TH, int NREP);
 
 struct PoolParams { const void* in; void* out; int B, H, W, C, ld, in_coff, out_coff; };

@@ -174,6 +174,35 @@ void pack_conv_fold(int dtype, const ConvRow& rU, const ConvRow& rV, const ConvC
             }
 }
 
+// The stem (3 -> 16, k3 s2) inside stem_l1_kernel as a Toeplitz GEMM (conv.hip, phase 2): for output pixel p (0..3) of a 4-pixel
+// window and kernel row kh, fragment row co holds W'[k] = w[co][chn][kh][kw] at window element k = 6 p + 3 + 3 kw + m, where m is
+// the MEMORY position of the channel inside the pixel (m = chn, or 2 - chn when the kernel flips the channel order: swap_rb), and
+// zero elsewhere.  Layout [swap 0..1][p][kh][chunk][lane][VEC]; natural row order (one n-tile: 16 stem channels).
+size_t packed_stem_toeplitz_bytes(int dtype) { return (size_t)2 * 4 * 3 * (dtype == VTI_F16 ? 1 : 2) * 1024; }
+
+void pack_stem_toeplitz(int dtype, const ConvRow& r0, const float* w, const float* b, uint8_t* dst, float* bd) {
+    const bool f16 = dtype == VTI_F16;
+    const int KC = f16 ? 32 : 16, VEC = f16 ? 8 : 4, NCH = 32 / KC;
+    for (int sw = 0; sw < 2; ++sw)
+        for (int pp = 0; pp < 4; ++pp)
+            for (int kh = 0; kh < 3; ++kh)
+                for (int c = 0; c < NCH; ++c)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < VEC; ++j) {
+                            const int co = lane & 15, k = c * KC + (lane >> 4) * VEC + j;
+                            const int t = k - 6 * pp - 3;
+                            float v = 0.f;
+                            if (t >= 0 && t < 9 && co < r0.c2) {
+                                const int kw = t / 3, m = t % 3, chn = sw ? 2 - m : m;
+                                v = w[(((size_t)co * 3 + chn) * 3 + kh) * 3 + kw];
+                            }
+                            const size_t e = ((((((size_t)sw * 4 + pp) * 3 + kh) * NCH + c) * 64) + lane) * VEC + j;
+                            if (f16) ((_Float16*)dst)[e] = (_Float16)v;
+                            else ((float*)dst)[e] = v;
+                        }
+    for (int n = 0; n < 16; ++n) bd[n] = n < r0.c2 ? b[n] : 0.f;
+}
+
 // Layer 1 (16 -> 32, k3 s2) inside stem_l1_kernel: K = 9 taps x 16 channels walked in MFMA steps that pair taps.
 // fp16: step s, lane group g -> tap 2s + (g >> 1), channels 8 (g & 1) + j (j < 8); the 10th half-step is zero.
 // fp32: step s = tap s, channels 4 g + j (j < 4).  Layout [step][ntile 0..1][lane][VEC]; rows permuted as for NREP = 2.
@@ -274,6 +303,10 @@ std::string pack_weights(const Plan& plan, const void* blob, size_t nbytes, std:
             continue;
         }
         const Op& op = *op_of[i];
+        if (op.kind == OP_CONV0 && op.fused_l1 >= 0) {       // the stem inside stem_l1_kernel: banded (Toeplitz) fragments
+            pack_stem_toeplitz(plan.desc.dtype, r, w.data(), b.data(), wpk.data() + op.cfg.wpk_off, bias.data() + op.cfg.bias_off);
+            continue;
+        }
         pack_conv(plan.desc.dtype, r, op.kind == OP_CONV0, op.cfg, w.data(), b.data(), wpk.data() + op.cfg.wpk_off,
                   bias.data() + op.cfg.bias_off);
     }
