@@ -834,6 +834,7 @@ static hipError_t launch_t(int ks, int stride, int nrep, int mode, const ConvPar
 
 hipError_t launch_conv(int dtype, int ks, int stride, int nrep, int mode, const ConvParams& p, size_t lds_bytes,
                        hipStream_t st) {
+    if (p.pk == 4) return launch_conv_pk2(dtype, nrep, p, lds_bytes, st);
     if (p.pk == 3) return launch_bneck_pk(dtype, nrep, p, lds_bytes, st);
     if (p.pk == 2) return launch_conv1_pk(dtype, nrep, p, lds_bytes, st);
     if (p.pk) return launch_conv_pk(dtype, nrep, p, lds_bytes, st);

@@ -36,9 +36,36 @@ constexpr int PK_PWP = 24;        // slots per patch row
 constexpr int PK_TW = 20;         // tile width (pixels)
 constexpr int PK_ROWS = 4;        // tile rows per M-wave: 4 x 20 = 80 pixels = MREP m-tiles
 constexpr int PK_MAXD = 9;        // patch DMA instructions per wave and step (host checks)
+constexpr int PK_MAXD2 = 13;      // ... of the stride-2 kernel (its patch is ~4x the output tile)
 
 // `depth` patch stages (2..4): the loaders run depth - 1 steps ahead.  Weights: K <= 2 chunks stay resident (1 or 2 buffers);
 // more chunks travel with the patches, one buffer per stage.
+static size_t pk_stage_bytes(int TH, int S) { return S == 2 ? (size_t)(2 * TH + 1) * 2 * PK_PWP * 64 : (size_t)(TH + 2) * PK_PWP * 64; }
+size_t conv_pk2_lds_bytes(int TH, int WN, int NREP, int nchunks, int depth) {     // stride 2
+    const int nwbuf = nchunks > 2 ? depth : (nchunks > 1 ? 2 : 1);
+    return depth * pk_stage_bytes(TH, 2) + (size_t)nwbuf * WN * NREP * 9 * 1024 + (size_t)WN * NREP * 16 * 4;
+}
+bool conv_pk2_instantiated(int nrep, int wn) { return (nrep == 1 && wn == 4) || (nrep == 2 && wn == 2) || (nrep == 4 && wn == 1) || (nrep == 2 && wn == 1) || (nrep == 1 && wn == 2); }
+bool conv_pk2_fits(int TH, int WN, int NREP, int nchunks) {
+    if (TH % PK_ROWS || !conv_pk2_instantiated(NREP, WN)) return false;
+    const int ncomp = (TH / PK_ROWS) * WN;
+    if (ncomp < 1 || ncomp > 4) return false;
+    const int ndma = (int)(pk_stage_bytes(TH, 2) / 1024);
+    if ((ndma + ncomp - 1) / ncomp > PK_MAXD2) return false;
+    return conv_pk2_lds_bytes(TH, WN, NREP, nchunks, 2) <= 160 * 1024;
+}
+int conv_pk2_depth(int TH, int WN, int NREP, int nchunks) {
+    if (!conv_pk2_fits(TH, WN, NREP, nchunks)) return 0;
+    // default 2: in an A/B on one box the deeper rings made the whole forward ~0.7 % SLOWER (VTI_PK_DEPTH=3/4 to re-measure)
+    const char* cap = getenv("VTI_PK_DEPTH");
+    const int maxd = cap ? std::max(2, std::min(4, atoi(cap))) : 2;
+    const int ncomp = (TH / PK_ROWS) * WN;
+    const int per_step = ((int)(pk_stage_bytes(TH, 2) / 1024) + ncomp - 1) / ncomp + (nchunks > 2 ? (WN * NREP * 9 + ncomp - 1) / ncomp : 0);
+    int d = 2;
+    while (d < maxd && conv_pk2_lds_bytes(TH, WN, NREP, nchunks, d + 1) <= 160 * 1024 && per_step * (d - 1) <= 63) ++d;
+    return d;
+}
+
 size_t conv_pk_lds_bytes(int TH, int WN, int NREP, int nchunks, int depth) {
     const size_t stage = (size_t)(TH + 2) * PK_PWP * 64;
     const int nwbuf = nchunks > 2 ? depth : (nchunks > 1 ? 2 : 1);
@@ -49,8 +76,9 @@ size_t conv_pk_lds_bytes(int TH, int WN, int NREP, int nchunks) { return conv_pk
 // deepest ring (<= 4) that fits the 160 KiB of LDS and the counted-wait range; 0 = the geometry does not fit at all
 int conv_pk_depth(int TH, int WN, int NREP, int nchunks) {
     if (!conv_pk_fits(TH, WN, NREP, nchunks)) return 0;
+    // default 2: in an A/B on one box the deeper rings made the whole forward ~0.7 % SLOWER (VTI_PK_DEPTH=3/4 to re-measure)
     const char* cap = getenv("VTI_PK_DEPTH");
-    const int maxd = cap ? std::max(2, std::min(4, atoi(cap))) : 4;
+    const int maxd = cap ? std::max(2, std::min(4, atoi(cap))) : 2;
     const int ncomp = (TH / PK_ROWS) * WN;
     const int per_step = ((TH + 2) * PK_PWP / 16 + ncomp - 1) / ncomp + (nchunks > 2 ? (WN * NREP * 9 + ncomp - 1) / ncomp : 0);
     int d = 2;
@@ -83,11 +111,18 @@ template <> struct WaitVm<0> { static __device__ __forceinline__ void go(int) { 
 // output phase (py, px) = (wn >> 1, wn & 1) and runs the 2x2 window that starts at patch (py, px) over the SAME 4 x 20 low-resolution
 // pixels as its three siblings (4 taps instead of 9; both K chunks of the 128 KB of composed weights stay in LDS for the whole
 // launch, where the per-tile kernel re-stages 64 KB per chunk and tile); its epilogue is the fused 1x1 stage on the 2x grid.
-template <typename T, int NREP, int WN, int NREP2 = 0, bool FOLD = false>
+// S = 2: the stride-2 3x3 convs (model.3/5/7/16/19) on the same schedule.  The patch is (2 TH + 1) x 41 input pixels; in LDS a patch
+// row keeps its EVEN columns in slots 0..20 and its ODD columns in slots 24..43 (row pitch 48 slots), so the 16 consecutive output
+// pixels of an MFMA operand read 16 consecutive slots for every tap (dx = 0: even plane at px, 1: odd plane at px, 2: even plane at
+// px + 1) -- conflict-free with the same source-side swizzle as stride 1 (an interleaved image would put them 128 B apart: 8-way).
+template <typename T, int NREP, int WN, int NREP2 = 0, bool FOLD = false, int S = 1>
 __global__ __launch_bounds__(512) void conv3_pk(const ConvParams p) {
     using vec = typename Tr<T>::vec;
     constexpr int VEC = Tr<T>::VEC, KC = Tr<T>::KC, ES = (int)sizeof(T);
     constexpr int TAPS = FOLD ? 4 : 9, NTB = WN * NREP;
+    constexpr int PWP = S == 2 ? 2 * PK_PWP : PK_PWP;       // slots per patch row
+    constexpr int MAXD = S == 2 ? PK_MAXD2 : PK_MAXD;
+    static_assert(S == 1 || (S == 2 && !FOLD && NREP2 == 0), "stride 2: plain epilogue only");
     constexpr int WCHUNK = NTB * TAPS * 1024;
     constexpr unsigned OOB = 0x80000000u;
     constexpr bool FAST = sizeof(T) == 2;
@@ -98,9 +133,9 @@ __global__ __launch_bounds__(512) void conv3_pk(const ConvParams p) {
     static_assert(!FOLD || (WN == 4 && NREP2 > 0), "fold: one compute wave per output phase, fused 1x1 epilogue");
     const int ncomp = (p.TH / PK_ROWS) * WN;                // compute waves; the other blockDim/64 - ncomp waves load
     const int nld = (int)(blockDim.x >> 6) - ncomp;
-    const int PH = p.TH + 2;
-    const int stage_bytes = PH * PK_PWP * 64;
-    const int ndma = PH * PK_PWP / 16;
+    const int PH = S == 2 ? 2 * p.TH + 1 : p.TH + 2;
+    const int stage_bytes = PH * PWP * 64;
+    const int ndma = PH * PWP / 16;
     const int D = p.pk_depth;                               // patch stages (ring depth)
     const bool stream_w = p.nchunks > 2;
     const int wbuf_off = D * stage_bytes;
@@ -142,22 +177,28 @@ __global__ __launch_bounds__(512) void conv3_pk(const ConvParams p) {
         // which holds channel piece q (source-side swizzle)
         const int q = (lane & 3) ^ (((lane >> 4) & 1) << 1);
         const int cvalid = (p.Cin - q * VEC + KC - 1) / KC;         // chunks in which this lane's channel piece exists
-        int dyx[PK_MAXD];
+        int dyx[MAXD];
 #pragma unroll
-        for (int u = 0; u < PK_MAXD; ++u) {
+        for (int u = 0; u < MAXD; ++u) {
             const int s = (lw + u * nld) * 16 + (lane >> 2);
-            const int py = (int)(((unsigned)s * 2731u) >> 16), px = s - py * PK_PWP;    // s / 24 for s < 4096
-            dyx[u] = px < PK_TW + 2 ? (py << 8) | px : -1;
+            if constexpr (S == 2) {
+                const int py = (int)(((unsigned)s * 1366u) >> 16), r = s - py * PWP;     // s / 48 for s < 4096
+                const int plane = r >= PK_PWP ? 1 : 0, idx = r - plane * PK_PWP;           // even columns first, then the odd ones
+                dyx[u] = idx < PK_TW + 1 - plane ? (py << 8) | (2 * idx + plane) : -1;
+            } else {
+                const int py = (int)(((unsigned)s * 2731u) >> 16), px = s - py * PK_PWP;    // s / 24 for s < 4096
+                dyx[u] = px < PK_TW + 2 ? (py << 8) | px : -1;
+            }
         }
         const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)p.in_bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.wpk, 0, (int)p.wpk_bytes, 0x00020000);
-        unsigned voff[PK_MAXD];
+        unsigned voff[MAXD];
         auto setup_voff = [&](int tt) {
             int b, oy0, ox0;
             tile_coords(tt, b, oy0, ox0);
 #pragma unroll
-            for (int u = 0; u < PK_MAXD; ++u) {
-                const int y = oy0 - 1 + (dyx[u] >> 8), x = ox0 - 1 + (dyx[u] & 255);
+            for (int u = 0; u < MAXD; ++u) {
+                const int y = S * oy0 - 1 + (dyx[u] >> 8), x = S * ox0 - 1 + (dyx[u] & 255);
                 const bool ok = dyx[u] >= 0 && (unsigned)y < (unsigned)p.Hin && (unsigned)x < (unsigned)p.Win;
                 voff[u] = ok ? (unsigned)((((b * p.Hin + y) * p.Win + x) * p.in_ld + p.in_coff + q * VEC) * ES) : OOB;
             }
@@ -166,7 +207,7 @@ __global__ __launch_bounds__(512) void conv3_pk(const ConvParams p) {
             const bool qok = c < cvalid;
             const unsigned dst = lds0 + stage * stage_bytes + lw * 1024;
 #pragma unroll
-            for (int u = 0; u < PK_MAXD; ++u)
+            for (int u = 0; u < MAXD; ++u)
                 if (lw + u * nld < ndma)
                     dma16(rsA, qok ? voff[u] : OOB, (unsigned)(c * KC * ES), dst + u * nld * 1024);
         };
@@ -181,7 +222,7 @@ __global__ __launch_bounds__(512) void conv3_pk(const ConvParams p) {
         }
         int per_step = 0;
 #pragma unroll
-        for (int u = 0; u < PK_MAXD; ++u) per_step += (lw + u * nld < ndma) ? 1 : 0;
+        for (int u = 0; u < MAXD; ++u) per_step += (lw + u * nld < ndma) ? 1 : 0;
         if (stream_w && lw < NTB * TAPS) per_step += (NTB * TAPS - lw + nld - 1) / nld;
         int it = t, ic = 0;                                 // (tile, chunk) of the next step to issue
         setup_voff(t);
@@ -218,7 +259,8 @@ __global__ __launch_bounds__(512) void conv3_pk(const ConvParams p) {
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) {
             // fold: window column b (= dx < 2) of phase column fpx is patch column px + fpx + b, window row a is patch row py + fpy + a
-            const int s = (ry[m] + fpy) * PK_PWP + px + fpx + dx;
+            const int s = S == 2 ? (2 * ry[m]) * PWP + (dx == 1 ? PK_PWP + px : px + (dx >> 1))      // input (2 y + dy, 2 x + dx), planes
+                                 : (ry[m] + fpy) * PK_PWP + px + fpx + dx;
             xa[m][dx] = (s * 64 + (lane >> 4) * 16) ^ ((s & 4) << 3);
         }
     }
@@ -257,7 +299,7 @@ __global__ __launch_bounds__(512) void conv3_pk(const ConvParams p) {
                 auto ldx = [&](int s_) -> vec {
                     const int tp = s_ / MREP, mm = s_ % MREP;
                     if constexpr (FOLD) return *(const vec*)(sx + xa[mm][tp & 1] + (tp >> 1) * (PK_PWP * 64));
-                    else return *(const vec*)(sx + xa[mm][tp % 3] + (tp / 3) * (PK_PWP * 64));
+                    else return *(const vec*)(sx + xa[mm][tp % 3] + (tp / 3) * (PWP * 64));
                 };
                 auto ldw = [&](int tp, vec (&w)[NREP]) {
 #pragma unroll
@@ -634,9 +676,9 @@ __global__ __launch_bounds__(512) void conv1_pk(const ConvParams p) {
     }
 }
 
-template <typename T, int NREP, int WN, int NREP2 = 0, bool FOLD = false>
+template <typename T, int NREP, int WN, int NREP2 = 0, bool FOLD = false, int S = 1>
 static hipError_t launch_pk_one(const ConvParams& p, dim3 grid, int threads, size_t lds, hipStream_t st) {
-    auto k = conv3_pk<T, NREP, WN, NREP2, FOLD>;
+    auto k = conv3_pk<T, NREP, WN, NREP2, FOLD, S>;
     static bool attr_done_dev[kMaxDevices] = {};
     bool& attr_done = attr_done_dev[current_device_slot()];
     if (!attr_done) {
@@ -718,8 +760,8 @@ hipError_t launch_conv1_pk(int dtype, int nrep, const ConvParams& p, size_t lds_
 // patch + both K chunks of the composed weights (2 x 16 n-tiles x 4 taps KiB) + the (unused) bias slot
 size_t conv_pk_fold_lds_bytes(int nchunks, int depth) { return depth * (size_t)6 * PK_PWP * 64 + (size_t)(nchunks > 1 ? 2 : 1) * 16 * 4 * 1024 + 16 * 16 * 4; }
 int conv_pk_fold_depth(int nchunks) {
-    const char* cap = getenv("VTI_PK_DEPTH");
-    const int maxd = cap ? std::max(2, std::min(4, atoi(cap))) : 4;
+    const char* cap = getenv("VTI_PK_FOLD_DEPTH");          // steps here are only ~1.3 k MFMA cycles long: a third stage keeps a patch in flight
+    const int maxd = cap ? std::max(2, std::min(4, atoi(cap))) : 3;
     int d = 2;
     while (d < maxd && conv_pk_fold_lds_bytes(nchunks, d + 1) <= 160 * 1024) ++d;
     return d;
@@ -738,6 +780,26 @@ hipError_t launch_conv_pk_fold(int dtype, const ConvParams& p, size_t lds_bytes,
     }
     VTI_FP(1) VTI_FP(2) VTI_FP(4)
 #undef VTI_FP
+    return hipErrorInvalidValue;
+}
+
+// stride-2 3x3 on the persistent schedule (p.pk == 4)
+hipError_t launch_conv_pk2(int dtype, int nrep, const ConvParams& p, size_t lds_bytes, hipStream_t st) {
+    const int NTB = p.WN * nrep;
+    if (p.TW != PK_TW || !conv_pk2_fits(p.TH, p.WN, nrep, p.nchunks) || p.ntiles2 > 0) return hipErrorInvalidValue;
+    if (p.pk_depth < 2 || p.pk_depth > 4 || lds_bytes < conv_pk2_lds_bytes(p.TH, p.WN, nrep, p.nchunks, p.pk_depth) || lds_bytes > 160 * 1024) return hipErrorInvalidValue;
+    if (p.ntiles_n % NTB || p.pk_wgs < 1 || (p.pk_xcd && p.pk_wgs % 8)) return hipErrorInvalidValue;
+    if ((size_t)p.in_bytes >= 0x80000000u || (size_t)p.out_bytes >= 0x80000000u) return hipErrorInvalidValue;
+    if (p.pk_tiles == 0) return hipSuccess;
+    const int threads = 2 * (p.TH / PK_ROWS) * p.WN * 64;
+    dim3 grid((unsigned)p.pk_wgs, (unsigned)(p.ntiles_n / NTB));
+#define VTI_L2(N, W)                                                                                           \
+    if (nrep == N && p.WN == W) {                                                                              \
+        if (dtype == VTI_F16) return launch_pk_one<half_t, N, W, 0, false, 2>(p, grid, threads, lds_bytes, st); \
+        return launch_pk_one<float, N, W, 0, false, 2>(p, grid, threads, lds_bytes, st);                        \
+    }
+    VTI_L2(1, 4) VTI_L2(2, 2) VTI_L2(4, 1) VTI_L2(2, 1) VTI_L2(1, 2)
+#undef VTI_L2
     return hipErrorInvalidValue;
 }
 
@@ -776,8 +838,9 @@ size_t bneck_pk_lds_bytes(int TH, int NREP) { return bneck_pk_lds_bytes(TH, NREP
 // patch stages: as many (<= 4) as fit -- these layers are HBM-bound and one 15-30 KB patch in flight per CU is ~1/3 of what
 // Little's law asks for at ~2 us of loaded latency
 int bneck_pk_depth(int TH, int NREP) {
+    // default 2: in an A/B on one box the deeper rings made the whole forward ~0.7 % SLOWER (VTI_PK_DEPTH=3/4 to re-measure)
     const char* cap = getenv("VTI_PK_DEPTH");
-    const int maxd = cap ? std::max(2, std::min(4, atoi(cap))) : 4;
+    const int maxd = cap ? std::max(2, std::min(4, atoi(cap))) : 2;
     const int nwm = TH / PK_ROWS;
     const int per_step = ((TH + 4) * PK_PWP / 16 + nwm - 1) / nwm;
     int d = 2;

@@ -155,6 +155,54 @@ static bool choose_pk_cfg(int esize, const ConvRow& r, int max_batch, ConvCfg& c
     return found;
 }
 
+// Stride-2 3x3 convs on the persistent schedule (conv3_pk<..., S = 2>): same cost model, the patch is (2 TH + 1) x 41 input pixels.
+static bool choose_pk2_cfg(int esize, const ConvRow& r, int max_batch, ConvCfg& c, int fth, int fwn, int fnrep) {
+    const char* no = getenv("VTI_NO_PK2");
+    if (no && no[0] == '1') return false;
+    if (!(r.k == 3 && r.s == 2 && r.kind == 0) || r.w_out < 20) return false;
+    double best = 1e30;
+    bool found = false;
+    const int tiles_x = (r.w_out + 19) / 20;
+    for (int WN = 1; WN <= 4; WN *= 2) {
+        if (fwn && WN != fwn) continue;
+        for (int NREP = 1; NREP <= 4; ++NREP) {
+            if (fnrep && NREP != fnrep) continue;
+            if (!conv_pk2_instantiated(NREP, WN)) continue;
+            const int NTB = WN * NREP;
+            const int gy = (c.ntiles_n + NTB - 1) / NTB;
+            const double n_eff = (double)c.ntiles_n / (gy * NTB);
+            if (n_eff < 0.74 && !fnrep) continue;
+            for (int NWM = 1; NWM <= 4; ++NWM) {
+                const int TH = 4 * NWM, ncomp = NWM * WN;
+                if (fth && TH != fth) continue;
+                if (ncomp > 4 || !conv_pk2_fits(TH, WN, NREP, c.nchunks)) continue;
+                const int tiles_y = (r.h_out + TH - 1) / TH;
+                const long NT = (long)max_batch * tiles_y * tiles_x;
+                long G = std::min<long>(NT, std::max(1, 256 / gy));
+                if (G >= 8) G &= ~7L;
+                const long rounds = (NT + G - 1) / G;
+                const int simd_load = (ncomp + 3) / 4;
+                const double lds_reads = 1.0 / NREP + 0.2;
+                const double mfma_cyc = (double)c.nchunks * 45 * NREP * 16 * std::max(1.0, lds_reads / 0.5);
+                const double t_comp = rounds * (mfma_cyc * simd_load + 1100.0 * NREP) / 1.9e9;
+                const double bytes = (double)NT * ((double)gy * (2 * TH + 1) * 41 * r.c1 + (double)TH * 20 * r.c2) * esize;
+                const double t_mem = bytes / 5.0e12;
+                const double cost = std::max(t_comp, t_mem) + 0.15 * std::min(t_comp, t_mem) + 4e-6;
+                if (cost < best) {
+                    best = cost; found = true;
+                    c.TH = TH; c.TW = 20; c.WN = WN; c.NREP = NREP; c.pk = 4; c.pk_wgpc = 1;
+                }
+            }
+        }
+    }
+    if (found) {
+        c.ntiles_n = (c.ntiles_n + c.WN * c.NREP - 1) / (c.WN * c.NREP) * (c.WN * c.NREP);
+        c.pk_depth = conv_pk2_depth(c.TH, c.WN, c.NREP, c.nchunks);
+        c.lds = conv_pk2_lds_bytes(c.TH, c.WN, c.NREP, c.nchunks, c.pk_depth);
+    }
+    return found;
+}
+
 // Geometry for the persistent 1x1 kernel (conv1_pk): tiles of (M-waves x 80) consecutive pixels, a deep stage ring,
 // weights stationary in LDS when all K chunks of the n-group fit in 64 KB.  These layers are HBM-bound: prefer one
 // n-group (the pixels are read once), then the deepest ring, then the fewest rounds.
@@ -223,6 +271,7 @@ void choose_conv_cfg(int dtype, const ConvRow& r, bool conv0, int max_batch, Con
     c.pk = 0;
     if (allow_pk && !conv0 && (!ftw || ftw == 80) && (!fth || fth <= 4) && choose_pk1_cfg(f16 ? 2 : 4, r, max_batch, c, fth, fwn, fnrep)) return;
     if (allow_pk && !conv0 && (!ftw || ftw == 20) && (!fth || fth % 4 == 0) && choose_pk_cfg(f16 ? 2 : 4, r, max_batch, c, fth, fwn, fnrep)) return;
+    if (allow_pk && !conv0 && (!ftw || ftw == 20) && (!fth || fth % 4 == 0) && choose_pk2_cfg(f16 ? 2 : 4, r, max_batch, c, fth, fwn, fnrep)) return;
     const int ks = deconv ? 1 : r.k, st = deconv ? 1 : r.s;
     const int Ho = deconv ? r.h_in : r.h_out, Wo = deconv ? r.w_in : r.w_out;
     c.TH = c.TW = 0;

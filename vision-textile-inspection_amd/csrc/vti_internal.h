@@ -59,7 +59,7 @@ struct ConvCfg {         // launch geometry chosen at plan time
     size_t wpk_off2 = 0, bias_off2 = 0;
     size_t wpk_off3 = 0, bias_off3 = 0;   // stem_l1_kernel with a fused 1x1 third conv: that conv's stage-2 pack (offsets 2 = layer 1)
     // persistent LDS-DMA kernel (conv_pk.hip): TW = 20, TH = 4 * M-waves; wgpc = co-resident workgroups per CU
-    int pk = 0, pk_wgpc = 1;         // pk: 1 = conv3_pk, 2 = conv1_pk (TH = compute waves along M, TW = 80), 3 = bneck_pk (fused 3x3 -> 3x3 pair)
+    int pk = 0, pk_wgpc = 1;         // pk: 1 = conv3_pk, 2 = conv1_pk (TH = compute waves along M, TW = 80), 3 = bneck_pk (fused 3x3 -> 3x3 pair), 4 = conv3_pk stride 2
     int pk_depth = 2, pk_wstat = 0;  // conv1_pk: stage-ring depth, weights stationary in LDS
 };
 
@@ -159,6 +159,12 @@ hipError_t launch_conv_pk(int dtype, int nrep, const ConvParams& p, size_t lds_b
 size_t conv_pk_lds_bytes(int TH, int WN, int NREP, int nchunks);
 size_t conv_pk_lds_bytes(int TH, int WN, int NREP, int nchunks, int depth);
 int conv_pk_depth(int TH, int WN, int NREP, int nchunks);
+// stride-2 3x3 on the persistent schedule (ConvCfg.pk == 4)
+hipError_t launch_conv_pk2(int dtype, int nrep, const ConvParams& p, size_t lds_bytes, hipStream_t st);
+size_t conv_pk2_lds_bytes(int TH, int WN, int NREP, int nchunks, int depth);
+bool conv_pk2_fits(int TH, int WN, int NREP, int nchunks);
+bool conv_pk2_instantiated(int nrep, int wn);
+int conv_pk2_depth(int TH, int WN, int NREP, int nchunks);
 bool conv_pk_fits(int TH, int WN, int NREP, int nchunks);
 bool conv_pk_instantiated(int nrep, int wn);
 hipError_t launch_conv1_pk(int dtype, int nrep, const ConvParams& p, size_t lds_bytes, hipStream_t st);
