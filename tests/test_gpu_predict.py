@@ -79,6 +79,32 @@ def test_predict_reference_call_shape(dtype):
     assert (first is None) == (ref0 is None) and (first is None or np.array_equal(first.cpu().numpy(), ref0))
 
 
+def test_fp16_engine_drift_against_the_fp32_oracle():
+    """The BENCHMARKED dtype against the fp32 CPU oracle, end to end (boxes AND masks), with the tolerance it actually meets written
+    down.  north_star asks IoU >= 0.999 / |d box| < 1e-3: the fp32 engine meets that (test above and bench.py's fp32_engine line);
+    fp16 storage of weights and of 76 layers of activations drifts by a few fp16 ulps per layer, which on these seeded random nets
+    (no trained margin between classes) means: boxes within 4 px (0.6 % of the 640-px frame; measured 1.4-1.9), >= 95 % of the
+    oracle's instances kept with the same class, mean mask IoU >= 0.98 over the matched ones (measured 0.995), worst one >= 0.8."""
+    need_gpu()
+    import vti_amd
+    from oracle import parity as op
+    fr = frames_u8(2, 640, 640, seed=23)
+    model = _calibrated_model(vti_amd, 80, "fp16", fr[0], 640, 0.25, target=60)
+    eng = model._engine(640, 640, 2)
+    got = op.engine_predict(eng, torch.from_numpy(fr).cuda(), 0.25, 0.7, 300)
+    want = op.oracle_predict(model._blob, fr, 80, 0.25, 0.7, 300, mode="fp32")
+    res = op.compare(got, want, 640, 640)
+    assert res["n_instances"] >= 20, res
+    assert res["n_matched"] >= 0.95 * res["n_instances"] and abs(res["n_engine"] - res["n_instances"]) <= 0.1 * res["n_instances"], res
+    assert res["box_px_max"] < 4.0 and res["conf_abs_max"] < 3e-2, res
+    assert res["mask_iou_mean"] >= 0.98 and res["mask_iou_min"] >= 0.8, res
+    # ... and the same pipeline on the exact-f32 engine meets the north-star gate itself
+    m32 = vti_amd.YOLO(model._blob, dtype="fp32", max_batch=2)
+    got32 = op.engine_predict(m32._engine(640, 640, 2), torch.from_numpy(fr).cuda(), 0.25, 0.7, 300)
+    r32 = op.compare(got32, want, 640, 640)
+    assert r32["meets_north_star"] and r32["mask_iou_min"] >= 0.999 and r32["box_norm_max"] < 1e-3 and r32["kept_set_equal"], r32
+
+
 def test_predict_batch_640_and_empty_results():
     need_gpu()
     import vti_amd
