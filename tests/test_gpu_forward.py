@@ -51,7 +51,8 @@ def test_layerwise_parity(scale, nc, H, W, B, dtype, tol):
             # 1x1 stage also does DFL + dist2bbox: checked via pred below
             # ... and proto.upsample when the plan folded it into proto.cv2 (four 2x2 convs on the low-resolution map): checked
             # through proto.cv3's output
-            assert (t["fused"] and (".cv3." in t["name"] or ".cv4." in t["name"] or (dtype == "fp16" and ".cv2." in t["name"]))) or \
+            # ... and the second 3x3 of a bottleneck whose C2f's closing 1x1 runs in the same kernel (y2 stays in registers)
+            assert (t["fused"] and (".cv3." in t["name"] or ".cv4." in t["name"] or ".m." in t["name"] or (dtype == "fp16" and ".cv2." in t["name"]))) or \
                    t["name"] == "model.22.proto.upsample", t["name"]
             continue
         checked += 1
@@ -59,7 +60,7 @@ def test_layerwise_parity(scale, nc, H, W, B, dtype, tol):
         assert got.shape == ref.shape and torch.isfinite(ref).all(), t["name"]
         err = (got - ref).abs().max().item()
         assert err <= tol * max(ref.abs().max().item(), 1.0), f"{t['name']}: max|d|={err:.3e} ref max={ref.abs().max():.3e}"
-    assert checked >= len(table) - 27      # n-scale fp16: stem + layer 1, 10 fused 3x3 mids, 9 tower outputs that live in pred only
+    assert checked >= len(table) - 28      # n-scale fp16: stem + layer 1, 10 fused 3x3 mids, 9 tower outputs that live in pred only
     assert pred.shape == opred.shape and torch.isfinite(pred).all()
     if scale != "n":
         return      # m/s random nets carry |logit| ~ 100: only the per-layer bound above is meaningful there

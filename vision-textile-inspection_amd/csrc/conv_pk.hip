@@ -855,8 +855,14 @@ bool bneck_pk_fits(int TH, int NREP) {
     return bneck_pk_lds_bytes(TH, NREP) <= 160 * 1024;
 }
 
-template <typename T, int NREP>
+// TAIL (fp16, C = 16: the n = 1 C2f of model.2): the C2f's closing 1x1 conv over [y0 | y1 | y2] runs here too.  The patch then carries
+// y0 AND y1 (one full 64-byte slot per pixel; conv 1's weights sit at K positions 16..31), and after conv 2's epilogue the wave holds
+// y2 of its pixels in registers: out = silu(Wa . [y0, y1](from the patch) + Wb . y2(from registers) + b) as two more MFMA steps per
+// (m-tile, n-tile) -- y2 is neither written nor re-read, the whole Y tensor is read once, and model.2.cv2's own launch disappears.
+// ConvParams: in_coff = y0's offset, w0 = [Wa tile 0, Wa tile 1, Wb tile 0, Wb tile 1] fragments, bias0 = the 1x1's bias, out2 = its output.
+template <typename T, int NREP, bool TAIL = false>
 __global__ __launch_bounds__(512) void bneck_pk(const ConvParams p) {
+    static_assert(!TAIL || (sizeof(T) == 2 && NREP == 1), "tail: fp16, 16 channels");
     using vec = typename Tr<T>::vec;
     constexpr int VEC = Tr<T>::VEC, ES = (int)sizeof(T);
     constexpr int TAPS = 9, R1W = PK_TW + 2;
@@ -905,7 +911,7 @@ __global__ __launch_bounds__(512) void bneck_pk(const ConvParams p) {
         const int lw = wave - nwm, nld = nwm;
         const int ndma = PH * PK_PWP / 16;
         const int q = (lane & 3) ^ (((lane >> 4) & 1) << 1);
-        const bool qok = q * VEC < p.Cin;                   // one chunk: channel pieces beyond Cin are written as zeros
+        const bool qok = q * VEC < (TAIL ? 2 * p.Cin : p.Cin);   // one chunk: channel pieces beyond Cin are written as zeros (tail: y0 | y1)
         int dyx[PK_MAXD];
 #pragma unroll
         for (int u = 0; u < PK_MAXD; ++u) {
@@ -973,6 +979,7 @@ __global__ __launch_bounds__(512) void bneck_pk(const ConvParams p) {
     }
     // phase 2 operand addresses (as conv3_pk, on the T image whose origin is the tile origin - 1)
     int xa2[MREP][3], ry[MREP], rx[MREP], ra[MREP];
+    [[maybe_unused]] int xc[MREP];
 #pragma unroll
     for (int m = 0; m < MREP; ++m) {
         const int pp = m * 16 + (lane & 15);
@@ -984,9 +991,21 @@ __global__ __launch_bounds__(512) void bneck_pk(const ConvParams p) {
             xa2[m][dx] = timg_off + ((s * 64 + g * 16) ^ ((s & 4) << 3));
         }
         const int sr = (ry[m] + 2) * PK_PWP + px + 2;       // the pixel itself in the input patch (shortcut)
-        const int piece = (sizeof(T) == 2 && NREP == 1) ? (g >> 1) : g;
+        const int piece = ((sizeof(T) == 2 && NREP == 1) ? (g >> 1) : g) + (TAIL ? 2 : 0);      // tail: y1 is the slot's upper half
         ra[m] = ((sr * 64 + piece * 16) ^ ((sr & 4) << 3)) + ((sizeof(T) == 2 && NREP == 1) ? (g & 1) * 8 : 0);
+        xc[m] = (sr * 64 + g * 16) ^ ((sr & 4) << 3);       // tail: the pixel's [y0 | y1] as an MFMA operand (k-group g = piece g)
     }
+    [[maybe_unused]] vec wA[2], wB[2];
+    [[maybe_unused]] f32x4 b3r[2];
+    if constexpr (TAIL) {
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            wA[n] = ((const vec*)p.w0)[n * 64 + lane];
+            wB[n] = ((const vec*)p.w0)[(2 + n) * 64 + lane];
+            b3r[n] = *(const f32x4*)(p.bias0 + g * 8 + 4 * n);      // permuted rows (NREP2 = 2): lane group g owns channels 8 g .. 8 g + 7
+        }
+    }
+    const __amdgpu_buffer_rsrc_t rsO2 = __builtin_amdgcn_make_buffer_rsrc(p.out2, 0, TAIL ? (int)p.out2_bytes : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)p.out_bytes, 0x00020000);
     const int crun = g * 4 * NREP;
     f32x4 b1r[NREP], b2r[NREP];
@@ -1129,7 +1148,26 @@ __global__ __launch_bounds__(512) void bneck_pk(const ConvParams p) {
                         v[0] += *(const f32x4*)(sx + ra[m]);
                     }
                 }
-                if constexpr (sizeof(T) == 2 && NREP == 2) {
+                if constexpr (TAIL) {
+                    // y2 of this pixel (rounded to T as it would have been stored) is the K operand of the second tail step:
+                    // elements 0..3 = channels 4 g .. 4 g + 3 (pack_conv_stage2's K order for a one-tile producer), 4..7 = 0
+                    vec xB;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { xB[j] = (T)v[0][j]; xB[4 + j] = (T)0; }
+                    const vec xA = *(const vec*)(sx + xc[m]);
+                    f32x4 a3[2];
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) {
+                        a3[n] = mma(wA[n], xA, (f32x4){0.f, 0.f, 0.f, 0.f});
+                        a3[n] = mma(wB[n], xB, a3[n]);
+                        a3[n] = silu4<FAST>(a3[n] + b3r[n]);
+                    }
+                    half8 hv;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { hv[j] = (half_t)a3[0][j]; hv[4 + j] = (half_t)a3[1][j]; }
+                    const unsigned ob2 = (unsigned)((opix * p.out2_ld + p.out2_coff + g * 8) * ES);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hv), rsO2, pv ? ob2 : OOB, 0u, 0);
+                } else if constexpr (sizeof(T) == 2 && NREP == 2) {
                     half8 hv;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) { hv[j] = (half_t)v[0][j]; hv[4 + j] = (half_t)v[1][j]; }
@@ -1153,9 +1191,9 @@ __global__ __launch_bounds__(512) void bneck_pk(const ConvParams p) {
     VTI_STAMP(12);
 }
 
-template <typename T, int NREP>
+template <typename T, int NREP, bool TAIL = false>
 static hipError_t launch_bneck_one(const ConvParams& p, dim3 grid, int threads, size_t lds, hipStream_t st) {
-    auto k = bneck_pk<T, NREP>;
+    auto k = bneck_pk<T, NREP, TAIL>;
     static bool done_dev[kMaxDevices] = {};
     bool& done = done_dev[current_device_slot()];
     if (!done) {
@@ -1172,13 +1210,17 @@ hipError_t launch_bneck_pk(int dtype, int nrep, const ConvParams& p, size_t lds_
         return hipErrorInvalidValue;
     if (p.Hin != p.Hout || p.Win != p.Wout || p.pk_wgs < 1 || (p.pk_xcd && p.pk_wgs % 8)) return hipErrorInvalidValue;
     if ((size_t)p.in_bytes >= 0x80000000u || (size_t)p.out_bytes >= 0x80000000u) return hipErrorInvalidValue;
-    if (p.has_res && (p.res != p.in || p.res_ld != p.in_ld || p.res_coff != p.in_coff)) return hipErrorInvalidValue;   // shortcut = the input
+    const int tail = p.w0 != nullptr;                       // the C2f's closing 1x1 in the same kernel (in_coff is then y0's offset)
+    if (tail && (dtype != VTI_F16 || nrep != 1 || !p.out2 || !p.bias0 || p.Cout2 != 32 || ((p.out2_ld | p.out2_coff) & 7) || (p.in_coff & 7)))
+        return hipErrorInvalidValue;
+    if (p.has_res && (p.res != p.in || p.res_ld != p.in_ld || p.res_coff != p.in_coff + (tail ? p.Cin : 0))) return hipErrorInvalidValue;   // shortcut = the input
     if ((p.out_ld | p.out_coff) & (dtype == VTI_F16 ? 7 : 3)) return hipErrorInvalidValue;                              // 16-byte stores
     if (p.pk_depth < 2 || p.pk_depth > 4 || lds_bytes < bneck_pk_lds_bytes(p.TH, nrep, p.pk_depth) || lds_bytes > 160 * 1024) return hipErrorInvalidValue;
     if (p.pk_tiles == 0) return hipSuccess;
     const int threads = 2 * (p.TH / PK_ROWS) * 64;
     dim3 grid((unsigned)p.pk_wgs, 1);
     if (dtype == VTI_F16) {
+        if (nrep == 1 && tail) return launch_bneck_one<half_t, 1, true>(p, grid, threads, lds_bytes, st);
         if (nrep == 1) return launch_bneck_one<half_t, 1>(p, grid, threads, lds_bytes, st);
         if (nrep == 2) return launch_bneck_one<half_t, 2>(p, grid, threads, lds_bytes, st);
     } else if (nrep == 1) {
@@ -1186,5 +1228,6 @@ hipError_t launch_bneck_pk(int dtype, int nrep, const ConvParams& p, size_t lds_
     }
     return hipErrorInvalidValue;
 }
+
 
 }  // namespace vti

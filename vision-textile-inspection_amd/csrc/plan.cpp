@@ -270,7 +270,9 @@ void choose_conv_cfg(int dtype, const ConvRow& r, bool conv0, int max_batch, Con
     c.nchunks = conv0 ? (32 / KC) : (r.c1 + KC - 1) / KC;
     c.pk = 0;
     if (allow_pk && !conv0 && (!ftw || ftw == 80) && (!fth || fth <= 4) && choose_pk1_cfg(f16 ? 2 : 4, r, max_batch, c, fth, fwn, fnrep)) return;
-    if (allow_pk && !conv0 && (!ftw || ftw == 20) && (!fth || fth % 4 == 0) && choose_pk_cfg(f16 ? 2 : 4, r, max_batch, c, fth, fwn, fnrep)) return;
+    if (allow_pk && !conv0 && (!ftw || ftw == 20) && (!fth || fth % 4 == 0) && choose_pk_cfg(f16 ? 2 : 4, r, max_batch, c, fth, fwn, fnrep)) {
+        return;
+    }
     if (allow_pk && !conv0 && (!ftw || ftw == 20) && (!fth || fth % 4 == 0) && choose_pk2_cfg(f16 ? 2 : 4, r, max_batch, c, fth, fwn, fnrep)) return;
     const int ks = deconv ? 1 : r.k, st = deconv ? 1 : r.s;
     const int Ho = deconv ? r.h_in : r.h_out, Wo = deconv ? r.w_in : r.w_out;
@@ -544,6 +546,29 @@ std::string Plan::build(const vti_desc& d) {
             a.out = b2.out; a.has_res = b2.has_res; a.res = b2.res;
             conv_out[a.conv].buf = -1;          // the intermediate is never materialised
             ops.erase(ops.begin() + i + 1);
+            // ... and, for an n = 1 C2f with c = 16 (fp16: [y0 | y1] is exactly one 64-byte slot), its closing 1x1 over [y0 | y1 | y2]:
+            // the tail of bneck_pk.  Y = [y0 | y1 | y2] in one buffer; the pair reads y1 (shortcut too) and would write y2.
+            const char* nt = getenv("VTI_NO_BNECK_TAIL");
+            if (!(nt && nt[0] == '1') && d.dtype == VTI_F16 && ra.c1 == 16 && i + 1 < ops.size()) {
+                Op& a2 = ops[i];
+                const Op& c3 = ops[i + 1];
+                const int Y = a2.in.buf, c = ra.c1;
+                if (c3.kind == OP_CONV && c3.lane == a2.lane && c3.fused < 0 && !c3.has_res && !c3.out_f32 && c3.up_C == 0) {
+                    const ConvRow& rc = convs[c3.conv];
+                    bool ok = rc.k == 1 && rc.s == 1 && rc.kind == 0 && rc.c1 == 3 * c && rc.c2 == 32 && bufs[Y].C == 3 * c &&
+                              c3.in.buf == Y && c3.in.coff == 0 && c3.in.C == 3 * c && a2.in.coff == c && a2.out.buf == Y && a2.out.coff == 2 * c &&
+                              a2.has_res && ((bufs[c3.out.buf].C | c3.out.coff) % 8) == 0 && bufs[c3.out.buf].bytes < pk_limit;
+                    for (size_t j = 0; ok && j < ops.size(); ++j)     // nobody else may read y2 (it will not exist)
+                        if (j != i && j != i + 1 && (ops[j].kind == OP_CONV || ops[j].kind == OP_UP2 || ops[j].kind == OP_POOL) &&
+                            (ops[j].in.buf == Y || (ops[j].has_res && ops[j].res.buf == Y)) &&
+                            !(ops[j].in.buf == Y && ops[j].in.coff + ops[j].in.C <= 2 * c && !(ops[j].has_res && ops[j].res.buf == Y))) ok = false;
+                    if (ok) {
+                        a2.tail = c3.conv; a2.out2 = c3.out;
+                        conv_out[a2.pair].buf = -1;             // y2 lives in registers only
+                        ops.erase(ops.begin() + i + 1);
+                    }
+                }
+            }
         }
     }
 
@@ -691,6 +716,12 @@ std::string Plan::build(const vti_desc& d) {
             op.cfg.wpk_off2 = woff; op.cfg.bias_off2 = boff;
             woff += packed_conv_bytes(convs[op.pair], false, op.cfg);
             boff += (size_t)op.cfg.ntiles_n * 16;
+        }
+        if (op.tail >= 0) {         // the C2f's closing 1x1 inside bneck_pk: Wa (2 fragments) + Wb (2 fragments), 32 biases
+            const ConvRow& rt = convs[op.tail];
+            macs += rt.macs(); fused_params += rt.fused_params();
+            op.cfg.wpk_off3 = woff; op.cfg.bias_off3 = boff;
+            woff += 4 * 1024; boff += 32;
         }
         if (op.fused_l1 >= 0) {
             const ConvRow& r1 = convs[op.fused_l1];

@@ -117,6 +117,8 @@ int32_t vti_conv_at(const vti_ctx* c, int32_t i, vti_conv_info* o) {
         if (op.conv == i) {
             o->tile_h = op.cfg.TH; o->tile_w = op.cfg.TW; o->waves_n = op.cfg.WN; o->nrep = op.cfg.NREP;
             o->lds_bytes = (int32_t)op.cfg.lds; o->persistent = op.cfg.pk;   // 1: conv3_pk, 2: conv1_pk, 3: bneck_pk
+        } else if (op.tail == i) {      // the C2f's closing 1x1 inside its bottleneck's kernel (bneck_pk tail)
+            o->tile_h = op.cfg.TH; o->tile_w = op.cfg.TW; o->waves_n = 1; o->nrep = 2; o->lds_bytes = 0; o->fused = 1; o->persistent = 1;
         } else if (op.pair == i) {      // second 3x3 of a fused Bottleneck: runs inside the first one's kernel (bneck_pk)
             o->tile_h = op.cfg.TH; o->tile_w = op.cfg.TW; o->waves_n = 1; o->nrep = op.cfg.NREP; o->lds_bytes = 0; o->fused = 1;
             o->persistent = 1;
@@ -309,7 +311,7 @@ int32_t vti_forward(vti_ctx* c, const uint8_t* input, int32_t B, int32_t swap_rb
             const bool cv = op.kind == OP_CONV || op.kind == OP_CONV0;
             fprintf(stderr, "[op %2d] lane %d %s%s%s\n", i++, op.lane,
                     cv ? P.convs[op.conv].name.c_str() : op.kind == OP_POOL ? "sppf_pool" : op.kind == OP_UP2 ? "upsample2x" : "decode",
-                    cv && op.fused_l1 >= 0 ? (" + " + P.convs[op.fused_l1].name).c_str() : cv && op.fold >= 0 ? (" (folded: " + P.convs[op.fold].name + ")").c_str() : cv && op.pair >= 0 ? (" + " + P.convs[op.pair].name).c_str() : "",
+                    cv && op.fused_l1 >= 0 ? (" + " + P.convs[op.fused_l1].name).c_str() : cv && op.fold >= 0 ? (" (folded: " + P.convs[op.fold].name + ")").c_str() : cv && op.pair >= 0 ? (" + " + P.convs[op.pair].name + (op.tail >= 0 ? " + " + P.convs[op.tail].name : "")).c_str() : "",
                     cv && op.fused >= 0 ? (" + " + P.convs[op.fused].name).c_str() : "");
         }
     }
@@ -439,6 +441,15 @@ int32_t vti_forward(vti_ctx* c, const uint8_t* input, int32_t B, int32_t swap_rb
                 p.w2 = (const char*)c->d_wpk + g.wpk_off2;
                 p.bias2 = c->d_bias + g.bias_off2;
                 if (p.pk != 3) return fail(c, VTI_ERR_UNSUPPORTED, "fused bottleneck needs the persistent kernel (tensor too large?)");
+                if (op.tail >= 0) {     // + the C2f's closing 1x1: the patch carries [y0 | y1] (in_coff = y0's offset), y2 is not stored
+                    const Buf& o2 = P.bufs[op.out2.buf];
+                    p.in_coff -= r.c1;
+                    p.w0 = (const char*)c->d_wpk + g.wpk_off3; p.bias0 = c->d_bias + g.bias_off3;
+                    p.out2 = buf_ptr(c, op.out2.buf, input, proto); p.out2_ld = o2.C; p.out2_coff = op.out2.coff; p.Cout2 = P.convs[op.tail].c2;
+                    const size_t o2b = (size_t)B * p.Hout * p.Wout * o2.C * P.esize;
+                    if (o2b >= 0x80000000ull) return fail(c, VTI_ERR_UNSUPPORTED, "fused bottleneck tail: output tensor too large");
+                    p.out2_bytes = (unsigned)o2b;
+                }
             }
             if (op.up_C > 0) {
                 const Buf& ub = P.bufs[op.up_src.buf];

@@ -70,6 +70,7 @@ struct Op {
     bool has_res = false;
     bool out_f32 = false;
     int fused = -1;      // conv index of a 1x1 conv fused into this op's epilogue (its own op is dropped)
+    int tail = -1;       // bneck_pk only: conv index of the C2f's closing 1x1 computed in the same kernel (out2 = its output; y2 is not stored)
     int pair = -1;       // conv index of the SECOND 3x3 of a fused C2f Bottleneck (bneck_pk): this op is the first; out/res are the second's
     int fold = -1;       // conv index of a ConvTranspose2d(2,2) FOLDED into this 3x3 conv (convfold_kernel): `in` is then the deconv's input
     int fused_l1 = -1;   // OP_CONV0 only: conv index of layer 1 computed by the same kernel (stem_l1_kernel); out/out2 = layer 1's view
@@ -122,7 +123,7 @@ struct ConvParams {
     float dfl_stride;
     // persistent kernel (conv_pk.hip): tile count, workgroups along x, XCD-contiguous tile ranges, tensor sizes
     int pk, pk_tiles, pk_wgs, pk_xcd, pk_depth, pk_wstat;
-    unsigned in_bytes, out_bytes, res_bytes;
+    unsigned in_bytes, out_bytes, res_bytes, out2_bytes;
     // conv1_pk: channels [0, up_C) come from in2 [B, Hout/2, Wout/2, in2_ld] at (y >> 1, x >> 1): the neck's Upsample + Concat folded into the loads
     const void* in2; int in2_ld, in2_coff, up_C; unsigned in2_bytes;
     int fold;                            // convfold_kernel: stage-2 output grid is 2 Hout x 2 Wout, stage-1 bias = p.bias[border class][64]
@@ -228,7 +229,7 @@ void choose_conv_cfg(int dtype, const ConvRow& r, bool conv0, int max_batch, Con
                      int th = 0, int tw = 0, int wn = 0, int nrep = 0, bool allow_pk = true);
 // weights.cpp: one conv's weights -> fragment order; dst_w has cfg.nchunks*ntiles_n*taps KiB, dst_b ntiles_n*16 floats
 void pack_conv(int dtype, const ConvRow& r, bool conv0, const ConvCfg& c, const float* w, const float* b,
-               uint8_t* dst_w, float* dst_b);
+               uint8_t* dst_w, float* dst_b, int cin_off = 0);      // cin_off: the conv's input channels sit at K positions cin_off.. of the chunk
 size_t packed_conv_bytes(const ConvRow& r, bool conv0, const ConvCfg& c);
 // fused second stage: the 1x1 conv `r2` packed against the accumulator layout of a producer with nrep1 cout tiles
 void pack_conv_stage2(int dtype, const ConvRow& r2, int nrep1, const float* w, const float* b, uint8_t* dst_w, float* dst_b,

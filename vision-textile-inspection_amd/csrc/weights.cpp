@@ -34,7 +34,7 @@ size_t packed_conv_bytes(const ConvRow& r, bool conv0, const ConvCfg& c) {
 }
 
 void pack_conv(int dtype, const ConvRow& r, bool conv0, const ConvCfg& c, const float* w, const float* b,
-               uint8_t* dst, float* bd) {
+               uint8_t* dst, float* bd, int cin_off) {
     const bool f16 = dtype == VTI_F16;
     const int KC = f16 ? 32 : 16, VEC = f16 ? 8 : 4;
     const bool deconv = r.kind == 2;
@@ -58,8 +58,8 @@ void pack_conv(int dtype, const ConvRow& r, bool conv0, const ConvCfg& c, const 
                                     const int q = ng / r.c2, co = ng % r.c2;
                                     v = w[((size_t)kk * r.c2 + co) * 4 + q];
                                 }
-                            } else if (kk < r.c1) {
-                                v = w[((size_t)ng * r.c1 + kk) * taps + tap];
+                            } else if (kk >= cin_off && kk - cin_off < r.c1) {
+                                v = w[((size_t)ng * r.c1 + (kk - cin_off)) * taps + tap];
                             }
                         }
                         const size_t e = ((((size_t)ck * c.ntiles_n + nt) * taps + tap) * 64 + lane) * VEC + j;
@@ -250,6 +250,9 @@ std::string pack_weights(const Plan& plan, const void* blob, size_t nbytes, std:
             if (op.fused_l1 >= 0) l1_host[op.fused_l1] = &op;
         }
 
+    std::vector<const Op*> tail_host(plan.convs.size(), nullptr);      // a C2f's closing 1x1 computed inside its bottleneck's kernel
+    for (const Op& op : plan.ops)
+        if (op.kind == OP_CONV && op.tail >= 0) tail_host[op.tail] = &op;
     std::vector<const Op*> pair_host(plan.convs.size(), nullptr);      // second 3x3 of a fused Bottleneck -> the op of the first
     for (const Op& op : plan.ops)
         if (op.kind == OP_CONV && op.pair >= 0) pair_host[op.pair] = &op;
@@ -276,6 +279,24 @@ std::string pack_weights(const Plan& plan, const void* blob, size_t nbytes, std:
         memcpy(w.data(), p + off, 4 * nw); off += 4 * nw;
         memcpy(b.data(), p + off, 4 * (size_t)r.c2); off += 4 * (size_t)r.c2;
 
+        if (tail_host[i]) {
+            // out = silu(Wa . [y0 | y1] + Wb . y2 + b): Wa = the first 2c input channels as an ordinary one-chunk 1x1 (rows permuted for
+            // two n-tiles), Wb = the last c against the producer's accumulator layout (one n-tile), 2 + 2 fragments
+            const ConvCfg& hc = tail_host[i]->cfg;
+            const int cb = plan.convs[tail_host[i]->conv].c1, ca = r.c1 - cb;       // c (y2), 2c (y0 | y1)
+            std::vector<float> wa((size_t)r.c2 * ca), wb((size_t)r.c2 * cb), zb(r.c2, 0.f), sink(64);
+            for (int o = 0; o < r.c2; ++o) {
+                for (int c2 = 0; c2 < ca; ++c2) wa[(size_t)o * ca + c2] = w[(size_t)o * r.c1 + c2];
+                for (int c2 = 0; c2 < cb; ++c2) wb[(size_t)o * cb + c2] = w[(size_t)o * r.c1 + ca + c2];
+            }
+            ConvRow ra = r; ra.c1 = ca;
+            ConvRow rb2 = r; rb2.c1 = cb;
+            ConvCfg ac; ac.nchunks = 1; ac.ntiles_n = 2; ac.NREP = 2; ac.gemm_n = r.c2;
+            uint8_t* dst = wpk.data() + hc.wpk_off3;
+            pack_conv(plan.desc.dtype, ra, false, ac, wa.data(), zb.data(), dst, sink.data());
+            pack_conv_stage2(plan.desc.dtype, rb2, 1, wb.data(), b.data(), dst + 2 * 1024, bias.data() + hc.bias_off3, false);
+            continue;
+        }
         if (pair_host[i]) {
             const ConvCfg& hc = pair_host[i]->cfg;
             pack_conv(plan.desc.dtype, r, false, hc, w.data(), b.data(), wpk.data() + hc.wpk_off2, bias.data() + hc.bias_off2);
@@ -303,6 +324,10 @@ std::string pack_weights(const Plan& plan, const void* blob, size_t nbytes, std:
             continue;
         }
         const Op& op = *op_of[i];
+        if (op.tail >= 0) {          // first 3x3 of a bottleneck with the fused tail: its input y1 is the UPPER half of the [y0 | y1] slot
+            pack_conv(plan.desc.dtype, r, false, op.cfg, w.data(), b.data(), wpk.data() + op.cfg.wpk_off, bias.data() + op.cfg.bias_off, r.c1);
+            continue;
+        }
         if (op.kind == OP_CONV0 && op.fused_l1 >= 0) {       // the stem inside stem_l1_kernel: banded (Toeplitz) fragments
             pack_stem_toeplitz(plan.desc.dtype, r, w.data(), b.data(), wpk.data() + op.cfg.wpk_off, bias.data() + op.cfg.bias_off);
             continue;
