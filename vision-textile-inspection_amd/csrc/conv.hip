@@ -23,6 +23,8 @@
 //    straight 1-KiB-per-fragment copy.
 //  * 256 threads = 4 waves; WN of them split N, 4/WN split M; each wave owns a 5 x NREP grid of
 //    16x16 accumulators (80 pixels x 16*NREP channels).
+#include <type_traits>
+
 #include "conv_dev.h"
 
 namespace vti {
@@ -117,39 +119,42 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvParams p) {   //
     // NREP == 5 kernels are at the register limit: they fetch the weight pieces synchronously inside commit()
     // (short-lived registers, L2-resident data) instead of carrying them across the MFMA loop.
     constexpr bool BPRE = NREP < 5;
-    vec ra[AR], rb[BR];
-    auto loadB = [&](int c) {
+    // Register sets of staged operands.  1x1 convs on the small maps are a chain of short K chunks (20 MFMAs each) whose cost is the
+    // memory round trip per chunk: they keep TWO chunks in flight (their staging registers are few: no taps, no halo).
+    constexpr int PD = (KS == 1 && BPRE) ? 2 : 1;
+    vec ra[PD][AR], rb[PD][BR];
+    auto loadB = [&](int c, vec (&rbs)[BR]) {
         const unsigned sB = (unsigned)(((size_t)c * p.ntiles_n + nt0) * (TAPS * 1024));
 #pragma unroll
         for (int u = 0; u < BR; ++u)
-            if (tid + u * 256 < NTB * TAPS * 64) rb[u] = buf_load16<vec>(rsB, (unsigned)(tid + u * 256) * 16u, sB);
+            if (tid + u * 256 < NTB * TAPS * 64) rbs[u] = buf_load16<vec>(rsB, (unsigned)(tid + u * 256) * 16u, sB);
     };
-    auto issue = [&](int c) {
+    auto issue = [&](int c, vec (&ras)[AR], vec (&rbs)[BR]) {
         const bool qok = c < cvalid;
 #pragma unroll
         for (int u = 0; u < AR; ++u)
             if (pix0 + 64 * u < ((npix + 7) & ~7))
-                ra[u] = buf_load16<vec>(rsA, qok ? aoff[u] : OOB, (unsigned)(c * KC * (int)sizeof(T)));
-        if constexpr (BPRE) loadB(c);
+                ras[u] = buf_load16<vec>(rsA, qok ? aoff[u] : OOB, (unsigned)(c * KC * (int)sizeof(T)));
+        if constexpr (BPRE) loadB(c, rbs);
     };
-    auto commit = [&](int c) {
-        if constexpr (!BPRE) loadB(c);
+    auto commit = [&](int c, vec (&ras)[AR], vec (&rbs)[BR]) {
+        if constexpr (!BPRE) loadB(c, rbs);
 #pragma unroll
         for (int u = 0; u < AR; ++u)
-            if (pix0 + 64 * u < npix) *(vec*)(smA + ldsA0 + u * 1024) = ra[u];
+            if (pix0 + 64 * u < npix) *(vec*)(smA + ldsA0 + u * 1024) = ras[u];
 #pragma unroll
         for (int u = 0; u < BR; ++u)
-            if (tid + u * 256 < NTB * TAPS * 64) *(vec*)(smB + (tid + u * 256) * 16) = rb[u];
+            if (tid + u * 256 < NTB * TAPS * 64) *(vec*)(smB + (tid + u * 256) * 16) = rbs[u];
     };
-
-    issue(0);
-    for (int c = 0; c < p.nchunks; ++c) {
+    // one K chunk: commit its operands (register set SET), refill that set with chunk c + PD, MFMA over the taps
+    auto chunk = [&](int c, auto set_c) {
+        constexpr int SET = decltype(set_c)::value;
         if (c < 2) VTI_STAMP(1 + 5 * c);
-        commit(c);                          // waits for this chunk's loads, fills LDS
+        commit(c, ra[SET], rb[SET]);        // waits for this chunk's loads, fills LDS
         if (c < 2) VTI_STAMP(3 + 5 * c);
         __syncthreads();
         if (c < 2) VTI_STAMP(4 + 5 * c);
-        if (c + 1 < p.nchunks) issue(c + 1);   // in flight during the MFMA loop below
+        if (c + PD < p.nchunks) issue(c + PD, ra[SET], rb[SET]);   // in flight during the MFMA loop(s) below
         // ---- MFMA over the taps of this chunk, software pipelined over the flat (tap, pixel-tile)
         // sequence: pixel fragments are read two steps ahead and the next tap's weight fragments one
         // whole tap ahead, so LDS latency hides under the 4-5 MFMAs of each step.
@@ -188,6 +193,17 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvParams p) {   //
         }
         if (c < 2) VTI_STAMP(5 + 5 * c);
         if (c + 1 < p.nchunks) __syncthreads();   // everyone is done reading LDS before it is refilled
+    };
+
+    issue(0, ra[0], rb[0]);
+    if constexpr (PD == 2) {
+        if (p.nchunks > 1) issue(1, ra[1], rb[1]);
+        for (int c = 0; c < p.nchunks; c += 2) {
+            chunk(c, std::integral_constant<int, 0>{});
+            if (c + 1 < p.nchunks) chunk(c + 1, std::integral_constant<int, 1>{});
+        }
+    } else {
+        for (int c = 0; c < p.nchunks; ++c) chunk(c, std::integral_constant<int, 0>{});
     }
 
     VTI_STAMP(11);
