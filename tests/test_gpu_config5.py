@@ -138,7 +138,7 @@ def test_nms_max_nms_cut_above_30000_candidates(m_engine):
 def test_persistent_kernels_fall_back_for_huge_tensors():
     """Tensors of >= 2 GiB cannot go through the persistent kernels (one buffer resource, bit 31 = out of range): the
     plan keeps such convs on the per-tile kernel and does not fold the Upsample.  Forced here by lowering the limit
-    (VTI_PK_LIMIT_BYTES) in a child process; outputs must be bit-identical to the normal plan's."""
+    (VTI_PK_LIMIT_BYTES) in a child process; outputs must agree with the normal plan's."""
     need_gpu()
     code = r'''
 import sys, os, numpy as np, torch
@@ -168,4 +168,8 @@ print("persistent", npk, "launches", eng.num_launches)
     l_a = int(outs[0][1].split()[3]); l_b = int(outs[1][1].split()[3])
     assert n_b < n_a, (outs[0][1], outs[1][1])             # fewer persistent launches ...
     assert l_b > l_a                                        # ... and the Upsample ops are back
-    assert np.array_equal(outs[0][0], outs[1][0])
+    # same network, other kernels: the per-tile / unfused kernels sum some K chunks in another order than the fused ones (the C2f tail
+    # of bneck_pk takes y2 from registers in the accumulator's channel order), so equal up to fp16 rounding drift, not bit for bit
+    a, b2 = outs[0][0], outs[1][0]
+    assert np.isfinite(a).all() and np.isfinite(b2).all()
+    assert np.abs(a - b2).max() <= 1e-2 * np.abs(a).max(), np.abs(a - b2).max()
