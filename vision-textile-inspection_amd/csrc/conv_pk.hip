@@ -216,10 +216,7 @@ __global__ __launch_bounds__(512) void conv3_pk(const ConvParams p) {
             const unsigned dst = lds0 + wbuf_off + wb * WCHUNK;
             for (int f = lw; f < NTB * TAPS; f += nld) dma16(rsB, (unsigned)lane * 16u, src + f * 1024, dst + f * 1024);
         };
-        if (!stream_w) {                                    // resident weights first: the oldest operations, covered by every counted wait
-            issue_weights(0, 0);
-            if (p.nchunks == 2) issue_weights(1, 1);
-        }
+        if (!stream_w) issue_weights(0, 0);                 // resident weights of chunk 0 first: the oldest operations
         int per_step = 0;
 #pragma unroll
         for (int u = 0; u < MAXD; ++u) per_step += (lw + u * nld < ndma) ? 1 : 0;
@@ -237,9 +234,16 @@ __global__ __launch_bounds__(512) void conv3_pk(const ConvParams p) {
         };
         const int ahead = min(D - 1, nsteps);
         for (int s = 0; s < ahead; ++s) issue_next(s);
+        // chunk 1's resident weights go out AFTER the first patches: step 0 starts as soon as chunk 0's weights and patch(0) are in,
+        // without waiting for the second half of the weights (36 of 72 KB on the 64-channel layers: ~2 k cycles of every launch)
+        int w1cnt = 0;
+        if (!stream_w && p.nchunks == 2) {
+            issue_weights(1, 1);
+            if (lw < NTB * TAPS) w1cnt = (NTB * TAPS - lw + nld - 1) / nld;
+        }
         for (int s = 0; s < nsteps; ++s) {
             const int inflight = min(D - 2, nsteps - 1 - s);
-            WaitVm<63>::go(min(63, inflight * per_step));
+            WaitVm<63>::go(min(63, inflight * per_step + (s == 0 ? w1cnt : 0)));
             __builtin_amdgcn_s_barrier();
             if (s + D - 1 < nsteps) issue_next(s + D - 1);
         }
@@ -293,7 +297,7 @@ __global__ __launch_bounds__(512) void conv3_pk(const ConvParams p) {
                 constexpr int NSTEP = TAPS * MREP;
                 // pixel fragments in flight: a step is NREP MFMAs (16 cycles each), an LDS read takes ~100+ cycles with 8 waves on
                 // the CU, so small register tiles need a deeper queue to keep the matrix pipe fed
-                constexpr int XD = NREP >= 4 ? 3 : NREP == 3 ? 4 : NREP == 2 ? 6 : 8, WD = 2;
+                constexpr int XD = NREP >= 5 ? 3 : NREP == 4 ? 5 : NREP == 3 ? 5 : NREP == 2 ? 6 : 8, WD = 2;
                 vec xq[XD];
                 vec wq[WD][NREP];
                 auto ldx = [&](int s_) -> vec {

@@ -130,7 +130,9 @@ static bool choose_pk_cfg(int esize, const ConvRow& r, int max_batch, ConvCfg& c
                 const long rounds = (NT + G - 1) / G;
                 const int simd_load = (ncomp * wgpc + 3) / 4;
                 const double lds_reads = 1.0 / NREP + 0.2;
-                const double mfma_cyc = (double)c.nchunks * 45 * NREP * 16 * std::max(1.0, lds_reads / 0.5);
+                // NREP = 5 keeps 100 accumulator registers and a shallow operand queue: measured 12 % behind two n-groups of 3
+                // (tools/pk_sweep.py: 64 -> 80 at 80 x 80: 61 vs 54 us), hence the factor (fitted so that the model flips where the sweep does)
+                const double mfma_cyc = (double)c.nchunks * 45 * NREP * 16 * std::max(1.0, lds_reads / 0.5) * (NREP == 5 ? 1.6 : 1.0);
                 const double t_comp = rounds * (mfma_cyc * simd_load + 1100.0 * NREP) / 1.9e9;   // a SIMD partner's MFMAs hide the epilogue
                 const double bytes = (double)NT * ((double)gy * (TH + 2) * 22 * r.c1 + (double)TH * 20 * r.c2) * esize;
                 const double t_mem = bytes / 5.0e12;
