@@ -116,6 +116,13 @@ def test_predict_batch_640_and_empty_results():
     assert torch.equal(one[0].boxes.data, res[1].boxes.data)
     assert torch.equal(one[0].masks.data_u8, res[1].masks.data_u8)
     assert model.names[0] == "class0" and len(model.names) == 80
+    # masks.xy (Utils/check_model.py:185): one polygon per instance inside the frame, every vertex a pixel of the mask
+    polys = one[0].masks.xy
+    m0 = one[0].masks.data_u8.cpu().numpy()
+    assert len(polys) == len(one[0].boxes)
+    for poly, m in list(zip(polys, m0))[:5]:
+        assert poly.dtype == np.float32 and poly.shape[1] == 2 and (len(poly) > 0) == bool(m.any())
+        assert poly[:, 0].min() >= 0 and poly[:, 0].max() <= 640 and all(m[int(y), int(x)] == 1 for x, y in poly)
     quiet = model.predict(fr[0], conf=0.999999)
     assert len(quiet[0].boxes) == 0 and quiet[0].masks is None and quiet[0].boxes.xyxy.shape == (0, 4)
 

@@ -16,6 +16,7 @@ import numpy as np
 import torch
 
 from .engine import Engine, unpack_bits
+from .polygons import masks2segments, scale_coords
 from .weights import random_weights, unpack_container
 
 
@@ -67,6 +68,7 @@ class Masks:
         self.orig_shape = orig_shape
         self._u8 = None
         self._f = None
+        self._xy = None
 
     @property
     def data_u8(self):
@@ -82,7 +84,13 @@ class Masks:
 
     @property
     def xy(self):
-        raise NotImplementedError("polygon masks (.xy) are not produced; use .data")
+        """One float32 [n,2] (x, y) polygon per instance in ORIGINAL frame pixels: the largest outer contour of the mask
+        (Ultralytics masks2segments + scale_coords; Utils/check_model.py:185-188 fills it).  Host side, computed on first use."""
+        if self._xy is None:
+            H, W = self.bits.shape[1], self._W
+            segs = masks2segments(self.data_u8.cpu().numpy())
+            self._xy = [scale_coords((H, W), s, self.orig_shape) for s in segs]
+        return self._xy
 
     def __len__(self):
         return self.bits.shape[0]
