@@ -543,57 +543,88 @@ __global__ __launch_bounds__(256) void mask_clear_kernel(const int* __restrict__
 
 __global__ __launch_bounds__(256) void mask_plan_kernel(const float* __restrict__ dets, const int* __restrict__ offsets, int B,
                                                         int max_det, int row, int H, int W, int capacity,
-                                                        int2* __restrict__ items, int* __restrict__ nitems,
-                                                        unsigned* __restrict__ csplit) {
+                                                        int2* __restrict__ items, int* __restrict__ nitems) {
     const int slot = blockIdx.x * 256 + threadIdx.x;
     const int total = min(offsets[B], capacity);
     if (slot >= total) return;
     int lo, inst;
     mask_slot_owner(offsets, B, slot, lo, inst);
     const float* d = dets + ((size_t)lo * max_det + inst) * row;
-    // fp16 prototypes, 32 coefficients: each fp32 coefficient c is split as c = h + l with h = half(c), l = half(c - h)
-    // (exact to 2^-22 |c|), packed in channel pairs, so the tile kernel's dots run as v_dot2_f32_f16 (products exact, fp32
-    // accumulation) at a quarter of the instructions of convert + fma.  Coefficients outside half range keep the fp32 path.
-    unsigned big = 0;
-    if (csplit && row == 6 + 32) {
-        unsigned* cs = csplit + (size_t)slot * 32;
-        float2 cf[16];                     // all 16 loads first: consumed inside the loop they would be waited for one by one
-#pragma unroll
-        for (int k = 0; k < 16; ++k) cf[k] = *(const float2*)(d + 6 + 2 * k);       // rows are 152 bytes: 8-byte aligned
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const float c0 = cf[k].x, c1 = cf[k].y;
-            if (!(fabsf(c0) < 3.0e4f) || !(fabsf(c1) < 3.0e4f)) big = 1u;
-            const half_t h0 = (half_t)c0, h1 = (half_t)c1;
-            const half_t l0 = (half_t)(c0 - (float)h0), l1 = (half_t)(c1 - (float)h1);
-            cs[k] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
-            cs[16 + k] = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
-        }
-    } else {
-        big = 1u;
-    }
     int tx0, tx1, ty0, ty1;
     if (!mask_tile_rect(d, H, W, tx0, tx1, ty0, ty1)) return;
     const int cnt = (tx1 - tx0 + 1) * (ty1 - ty0 + 1);
     int base = atomicAdd(nitems, cnt);
     for (int ty = ty0; ty <= ty1; ++ty)
-        for (int tx = tx0; tx <= tx1; ++tx) items[base++] = make_int2((slot << 12) | (ty << 6) | tx, (int)((big << 31) | ((unsigned)lo << 16) | (unsigned)inst));   // tiles < 64 per side
+        for (int tx = tx0; tx <= tx1; ++tx) items[base++] = make_int2((slot << 12) | (ty << 6) | tx, (int)(((unsigned)lo << 16) | (unsigned)inst));   // tiles < 64 per side
 }
 
-#ifdef VTI_STAMPS   // diagnostic build only: cycles per phase of masks_kernel, summed over the items of wave 0 of every block
-__device__ unsigned long long g_mask_acc[8];
-#define MASK_T(i) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
-                       macc[i] += t_ - mprev; mprev = t_; } while (0)
-#else
-#define MASK_T(i) do { } while (0)
-#endif
+// Bilinear 4x upsample + threshold of ONE instance's low-res tile `lw` (pitch ML + 1) for the 16 output rows of a wave; a LANE IS A
+// COLUMN (taps c0 / c1, weight lx1).  F.interpolate(bilinear, align_corners=False) at the fixed 1/4 scale: src = 0.25*(dst+0.5)-0.5
+// clamped at 0, so for dst >= 2 the source index is (dst-2)>>2 with fraction {0.125,0.375,0.625,0.875}[(dst-2)&3] and for dst < 2 it
+// is index 0, fraction 0 (all exact in fp32).  The horizontal blend is done once per low-res row (6 per wave), a pixel then costs one
+// vertical blend, a + w (b - a) as one FMA, and the 64-lane compare mask of a row IS that row's 8 output bytes, moved to lane r's
+// registers with v_writelane (the builtin, so the compiler fills the VALU->SGPR->writelane wait states with the next rows' blends).
+// `ro[j]`: offset of low-res row (first row >> 2) - 1 + j (clamped to the image) inside `lw`; `top`: the wave starts at image row 0.
+template <bool BYTES>
+__device__ __forceinline__ void mask_rows16(const float* lw, const int (&ro)[6], int c0, int c1, float lx1, bool top, float thr,
+                                            unsigned& lo, unsigned& hi, uint8_t* __restrict__ out_bytes, int W, int H, int yw, int xg) {
+    float hb[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const float a = lw[ro[j] + c0], b = lw[ro[j] + c1];
+        hb[j] = __builtin_fmaf(b - a, lx1, a);
+    }
+    unsigned l_ = 0u, h_ = 0u;
+    constexpr float FR[4] = {0.125f, 0.375f, 0.625f, 0.875f};
+#pragma unroll
+    for (int r0 = 0; r0 < 16; r0 += 8) {
+        unsigned ml[8], mh[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int r = r0 + q, j = (r + 2) >> 2;
+            float w1 = FR[(r + 2) & 3];
+            if (r < 2 && top) w1 = 0.0f;                                  // rows 0, 1 of the image clamp to source row 0
+            const float v = __builtin_fmaf(hb[j + 1] - hb[j], w1, hb[j]);
+            if constexpr (BYTES) {
+                if (xg < W && yw + r < H) out_bytes[(size_t)(yw + r) * W + xg] = v > thr ? (uint8_t)1 : (uint8_t)0;
+            } else {
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(v > thr);
+                ml[q] = (unsigned)m; mh[q] = (unsigned)(m >> 32);         // wave-uniform (SGPRs)
+            }
+        }
+        if constexpr (!BYTES) {
+            // the compares write SGPRs that v_writelane reads: the hardware needs wait states in between and the compiler's hazard
+            // recogniser does not look inside inline asm (seen as wrong bits in exactly the rows whose compare sat next to its
+            // writelane), so eight rows' masks are moved by one block behind one s_nop
+            if (r0 == 0)
+                asm("s_nop 4\n\tv_writelane_b32 %0, %2, 0\n\tv_writelane_b32 %1, %3, 0\n\tv_writelane_b32 %0, %4, 1\n\tv_writelane_b32 %1, %5, 1\n\t"
+                    "v_writelane_b32 %0, %6, 2\n\tv_writelane_b32 %1, %7, 2\n\tv_writelane_b32 %0, %8, 3\n\tv_writelane_b32 %1, %9, 3\n\t"
+                    "v_writelane_b32 %0, %10, 4\n\tv_writelane_b32 %1, %11, 4\n\tv_writelane_b32 %0, %12, 5\n\tv_writelane_b32 %1, %13, 5\n\t"
+                    "v_writelane_b32 %0, %14, 6\n\tv_writelane_b32 %1, %15, 6\n\tv_writelane_b32 %0, %16, 7\n\tv_writelane_b32 %1, %17, 7"
+                    : "+v"(l_), "+v"(h_)
+                    : "s"(ml[0]), "s"(mh[0]), "s"(ml[1]), "s"(mh[1]), "s"(ml[2]), "s"(mh[2]), "s"(ml[3]), "s"(mh[3]),
+                      "s"(ml[4]), "s"(mh[4]), "s"(ml[5]), "s"(mh[5]), "s"(ml[6]), "s"(mh[6]), "s"(ml[7]), "s"(mh[7]));
+            else
+                asm("s_nop 4\n\tv_writelane_b32 %0, %2, 8\n\tv_writelane_b32 %1, %3, 8\n\tv_writelane_b32 %0, %4, 9\n\tv_writelane_b32 %1, %5, 9\n\t"
+                    "v_writelane_b32 %0, %6, 10\n\tv_writelane_b32 %1, %7, 10\n\tv_writelane_b32 %0, %8, 11\n\tv_writelane_b32 %1, %9, 11\n\t"
+                    "v_writelane_b32 %0, %10, 12\n\tv_writelane_b32 %1, %11, 12\n\tv_writelane_b32 %0, %12, 13\n\tv_writelane_b32 %1, %13, 13\n\t"
+                    "v_writelane_b32 %0, %14, 14\n\tv_writelane_b32 %1, %15, 14\n\tv_writelane_b32 %0, %16, 15\n\tv_writelane_b32 %1, %17, 15"
+                    : "+v"(l_), "+v"(h_)
+                    : "s"(ml[0]), "s"(mh[0]), "s"(ml[1]), "s"(mh[1]), "s"(ml[2]), "s"(mh[2]), "s"(ml[3]), "s"(mh[3]),
+                      "s"(ml[4]), "s"(mh[4]), "s"(ml[5]), "s"(mh[5]), "s"(ml[6]), "s"(mh[6]), "s"(ml[7]), "s"(mh[7]));
+        }
+    }
+    lo = l_; hi = h_;
+}
 
-template <typename T, int NM>      // NM = compile-time coefficient count (32), 0 = use the runtime nm
+// Generic coefficient count (nm != 32): one work item per (instance slot, tile), vector-ALU dots.  The nm == 32 layout of every
+// YOLOv8-seg checkpoint runs masks_group_kernel below; this kernel is the reference-shaped fallback and shares its upsample.
+template <typename T>
 __global__ __launch_bounds__(256, 6) void masks_kernel(const float* __restrict__ dets, const int* __restrict__ offsets,
                                                     const T* __restrict__ proto, int B, int max_det, int nm, int Hp,
                                                     int Wp, int H, int W, int mode, int packing,
                                                     uint8_t* __restrict__ masks, const int2* __restrict__ items,
-                                                    const int* __restrict__ nitems, const unsigned* __restrict__ csplit) {
+                                                    const int* __restrict__ nitems) {
     __shared__ float coef[64];
     __shared__ float low[ML][ML + 1];
     const int tid = threadIdx.x;
@@ -606,10 +637,6 @@ __global__ __launch_bounds__(256, 6) void masks_kernel(const float* __restrict__
     const int per = (n + 7) >> 3;
     const int it0 = xcd * per + jx, it1 = min(n, (xcd + 1) * per);
     int2 itm_next = it0 < it1 ? items[it0] : make_int2(0, 0);
-#ifdef VTI_STAMPS
-    unsigned long long macc[6] = {0, 0, 0, 0, 0, 0}, mprev, mitems = 0;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(mprev)::"memory");
-#endif
     for (int it = it0; it < it1; it += nx) {
         const int2 itm = itm_next;
         {   // the next item's record is fetched a whole item ahead (clamped index: nothing consumes it in this iteration)
@@ -620,15 +647,11 @@ __global__ __launch_bounds__(256, 6) void masks_kernel(const float* __restrict__
         const int code = __builtin_amdgcn_readfirstlane(itm.y);
         const int tx = item & 63, ty = (item >> 6) & 63, slot = item >> 12;      // packed by mask_plan_kernel: no divisions here
         const int b = (code >> 16) & 0x7fff, inst = code & 0xffff;
-        const bool split_ok = code >= 0;  // bit 31: a coefficient outside half range (or no split table) -> fp32 dots
-        MASK_T(0);                        // item record decoded
         __syncthreads();                  // previous iteration is done with the shared tiles
-        MASK_T(1);
         const int y0 = ty * MT, x0 = tx * MT;
         const int row = 6 + nm;
         const float* d = dets + ((size_t)b * max_det + inst) * row;
-        const bool fast = NM == 32 && sizeof(T) == 2 && split_ok;        // block-uniform
-        if (!fast && tid < nm) coef[tid] = d[6 + tid];
+        if (tid < nm) coef[tid] = d[6 + tid];
 
         // torch: area_pixel_compute_scale<float>(in, out) = (float)in / out ; src = scale*(dst+0.5)-0.5, clamped at 0
         const float sh = (float)Hp / (float)H, sw = (float)Wp / (float)W;
@@ -638,61 +661,6 @@ __global__ __launch_bounds__(256, 6) void masks_kernel(const float* __restrict__
         // crop box in prototype pixels: boxes * (mw/iw) etc. in fp32 (torch multiplies an f32 tensor by a python float)
         const float wr = (float)((double)Wp / (double)W), hr = (float)((double)Hp / (double)H);
         const float bx1 = d[0] * wr, by1 = d[1] * hr, bx2 = d[2] * wr, by2 = d[3] * hr;
-        if constexpr (NM == 32 && sizeof(T) == 2) {
-            if (fast) {
-                // fp16 prototypes, split coefficients.  Two lanes share a low-res point (16 channels = 32 contiguous bytes each),
-                // so a wave instruction reads 2 KiB of contiguous prototype rows instead of 64 scattered 16-byte pieces (the
-                // per-point layout kept the CU's L1 at one access per cycle for the whole kernel: TCP_TOTAL_ACCESSES ~= cycles).
-                // All loads of the item are issued together, unconditionally and from clamped addresses, BEFORE anything is
-                // consumed (hipcc waits for a load that sits inside a branch; see conv.hip, stem_l1_kernel).
-                typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-                constexpr int RP = ML * 2, NP = ML * RP, NRD = (NP + 255) / 256;      // half-points per row / per tile, rounds
-                const int half = tid & 1;                                 // == idx & 1 in every round (RP and 256 are even)
-                const uint4* cs4 = (const uint4*)(csplit + (size_t)slot * 32);
-                const uint4 chv[2] = {cs4[half * 2], cs4[half * 2 + 1]}, clv[2] = {cs4[4 + half * 2], cs4[4 + half * 2 + 1]};
-                uint4 pv[NRD][2];
-                bool inb[NRD], wr[NRD];
-                int la[NRD];
-#pragma unroll
-                for (int u = 0; u < NRD; ++u) {
-                    const int idx = tid + 256 * u;
-                    const bool live = idx < NP;
-                    const int ic = live ? idx : 0;
-                    const int r = ic / RP, q = ic - r * RP, c = q >> 1;
-                    la[u] = r * (ML + 1) + c;
-                    wr[u] = live && half == 0;
-                    const int py = ly0 + r, px = lx0 + c;
-                    const float fr = (float)py, fc = (float)px;
-                    inb[u] = py < Hp && px < Wp && fc >= bx1 && fc < bx2 && fr >= by1 && fr < by2;
-                    const int pyc = py < Hp ? py : Hp - 1, pxc = px < Wp ? px : Wp - 1;
-                    const uint4* pp = (const uint4*)(proto + ((size_t)(b * Hp + pyc) * Wp + pxc) * 32 + half * 16);
-                    pv[u][0] = pp[0]; pv[u][1] = pp[1];
-                }
-                MASK_T(2);                // box loaded, prototype loads issued
-#pragma unroll
-                for (int u = 0; u < NRD; ++u) {
-                    float acc = 0.f, acc_l = 0.f;
-#pragma unroll
-                    for (int k = 0; k < 2; ++k) {
-                        const unsigned w[4] = {pv[u][k].x, pv[u][k].y, pv[u][k].z, pv[u][k].w};
-                        const unsigned ch[4] = {chv[k].x, chv[k].y, chv[k].z, chv[k].w}, cl[4] = {clv[k].x, clv[k].y, clv[k].z, clv[k].w};
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const h2 x = __builtin_bit_cast(h2, w[j]);
-                            acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, ch[j]), x, acc, false);
-                            acc_l = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, cl[j]), x, acc_l, false);
-                        }
-                    }
-                    acc += acc_l;
-                    // the other half of the point sits in the neighbouring lane (quad_perm [1,0,3,2])
-                    acc += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, acc), 0xB1, 0xF, 0xF, true));
-                    float v = mode == VTI_MASK_SIGMOID ? 1.0f / (1.0f + expf(-acc)) : acc;
-                    v = inb[u] ? v : 0.f;
-                    if (wr[u]) (&low[0][0])[la[u]] = v;
-                }
-            }
-        }
-        if (!fast) {
         __syncthreads();
         for (int e = tid; e < ML * ML; e += 256) {
             const int r = e / ML, c = e - r * ML;
@@ -705,15 +673,8 @@ __global__ __launch_bounds__(256, 6) void masks_kernel(const float* __restrict__
                     float acc = 0.f;
                     constexpr int PV = 16 / sizeof(T);          // 16-B pieces
                     typedef T pvec __attribute__((ext_vector_type(PV)));
-                    if constexpr (NM > 0) {
-                        // summation order is free here (torch's sgemm sums in its own order anyway)
-#pragma unroll
-                        for (int k = 0; k < NM; k += PV) {
-                            const pvec v = *(const pvec*)(pp + k);
-#pragma unroll
-                            for (int j = 0; j < PV; ++j) acc = __builtin_fmaf(d[6 + k + j], (float)v[j], acc);
-                        }
-                    } else if (nm % PV == 0) {
+                    // summation order is free here (torch's sgemm sums in its own order anyway)
+                    if (nm % PV == 0) {
                         for (int k = 0; k < nm; k += PV) {
                             const pvec v = *(const pvec*)(pp + k);
 #pragma unroll
@@ -727,18 +688,10 @@ __global__ __launch_bounds__(256, 6) void masks_kernel(const float* __restrict__
             }
             low[r][c] = v;
         }
-        }
-        MASK_T(3);                        // dots done, low-res tile written
         __syncthreads();
-        MASK_T(4);
 
         const float thr = mode == VTI_MASK_SIGMOID ? 0.5f : 0.0f;
-        // F.interpolate(bilinear, align_corners=False) at the fixed 1/4 scale: src = 0.25*(dst+0.5)-0.5 clamped at 0, so for
-        // dst >= 2 the source index is (dst-2)>>2 with fraction {0.125,0.375,0.625,0.875}[(dst-2)&3] and for dst < 2 it is
-        // index 0, fraction 0 (all exact in fp32: the same values the generic formula gives).
-        // A wave owns 16 rows of the tile and a LANE IS A COLUMN: its horizontal taps and weights are fixed, so the horizontal
-        // blend is done once per low-res row (6 per wave), a pixel then costs one vertical blend (torch's order: horizontal
-        // first) and the 64-lane compare mask of a row IS that row's 8 output bytes -- 3 VALU instructions per 64 pixels.
+        // a wave owns 16 rows of the tile (mask_rows16)
         const int wv = tid >> 6, ln = tid & 63;
         const int yw = __builtin_amdgcn_readfirstlane(y0 + 16 * wv);      // first row of this wave
         if (yw >= H) continue;
@@ -746,44 +699,20 @@ __global__ __launch_bounds__(256, 6) void masks_kernel(const float* __restrict__
         int k0 = xg >= 2 ? (xg - 2) >> 2 : 0;
         k0 = k0 < Wp - 1 ? k0 : Wp - 1;                                   // columns past W (partial tile) are masked below
         const int k1 = k0 + (k0 < Wp - 1 ? 1 : 0);
-        const float lx1 = xg >= 2 ? 0.125f + 0.25f * (float)((xg - 2) & 3) : 0.0f, lxw0 = 1.0f - lx1;
+        const float lx1 = xg >= 2 ? 0.125f + 0.25f * (float)((xg - 2) & 3) : 0.0f;
         const int rb = (yw >> 2) - 1;                                     // low-res row of (yw - 2) >> 2
-        float hb[6];
+        int ro[6];
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
             int rr = rb + j;
             rr = rr < 0 ? 0 : (rr > Hp - 1 ? Hp - 1 : rr);                // == min(iy + 1, Hp - 1) for the lower tap
-            rr -= ly0;
-            hb[j] = low[rr][k0 - lx0] * lxw0 + low[rr][k1 - lx0] * lx1;
+            ro[j] = (rr - ly0) * (ML + 1);
         }
         const int valid = W - x0;                                         // 32 or >= 64 (W is a multiple of 32)
         const unsigned long long cmask = valid >= 64 ? ~0ull : ((1ull << valid) - 1ull);
         unsigned lo = 0u, hi = 0u;
-        auto rows16 = [&](auto bytes) {                                   // two unrolled variants: no per-row branch on the packing
-            constexpr bool BYTES = decltype(bytes)::value;
-            unsigned l_ = 0u, h_ = 0u;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                constexpr float FR[4] = {0.125f, 0.375f, 0.625f, 0.875f};
-                const int j = (r + 2) >> 2;                               // low-res row of output row yw + r, relative to rb
-                float w1 = FR[(r + 2) & 3];
-                if (r < 2 && yw == 0) w1 = 0.0f;                          // rows 0, 1 of the image clamp to source row 0
-                const float v = hb[j] * (1.0f - w1) + hb[j + 1] * w1;
-                if constexpr (BYTES) {
-                    if (xg < W && yw + r < H) masks[((size_t)slot * H + yw + r) * W + xg] = v > thr ? (uint8_t)1 : (uint8_t)0;
-                } else {
-                    const unsigned long long m = __builtin_amdgcn_ballot_w64(v > thr);
-                    const unsigned mlo = (unsigned)m, mhi = (unsigned)(m >> 32);      // wave-uniform (SGPRs)
-                    // the compare writes VCC and v_writelane reads it as an SGPR operand: the hardware needs wait states in
-                    // between and the compiler's hazard recogniser does not look inside inline asm (seen as wrong bits in
-                    // exactly the rows whose compare sat next to its writelane)
-                    asm("s_nop 4\n\tv_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4"
-                        : "+v"(l_), "+v"(h_) : "s"(mlo), "s"(mhi), "n"(r));
-                }
-            }
-            lo = l_; hi = h_;
-        };
-        if (packing == VTI_PACK_U8) rows16(std::true_type{}); else rows16(std::false_type{});
+        if (packing == VTI_PACK_U8) mask_rows16<true>(&low[0][0], ro, k0 - lx0, k1 - lx0, lx1, yw == 0, thr, lo, hi, masks + (size_t)slot * H * W, W, H, yw, xg);
+        else mask_rows16<false>(&low[0][0], ro, k0 - lx0, k1 - lx0, lx1, yw == 0, thr, lo, hi, nullptr, W, H, yw, xg);
         lo &= (unsigned)cmask; hi &= (unsigned)(cmask >> 32);            // columns past W (partial tile)
         if (packing != VTI_PACK_U8 && ln < 16 && yw + ln < H) {           // lane r stores row r: 8 (4) bytes of bits
             const int wb = W >> 3;
@@ -791,21 +720,310 @@ __global__ __launch_bounds__(256, 6) void masks_kernel(const float* __restrict__
             o[0] = lo;
             if (valid >= 64) o[1] = hi;
         }
-#ifdef VTI_STAMPS
-        MASK_T(5); ++mitems;
+    }
+}
+
+// The same upsample with a LANE AS A ROW: one wave produces the whole 64 x 64 tile of one instance, every lane the 64 bits of its
+// row -- no transposition of compare masks (the 32 v_writelane per 16 rows of mask_rows16 go away) and 3 vector instructions per
+// 64 pixels: the blend, the compare, and v_addc (bits = 2 bits + carry-in) that shifts the compare's own bit into the lane's word;
+// pixels are taken from 31 down to 0 so that pixel 0 ends in bit 0.  The vertical blend comes first here (18 low-res columns per
+// lane), the horizontal one second with compile-time taps and weights: bilinear interpolation is separable, so this is the same
+// number as torch's horizontal-first order up to the last rounding (a pixel can differ only where the blended logit is within
+// ~1e-7 relative of the threshold).  `lrow`: &low[u][row of (y - 2) >> 2][first column]; the next low-res row is LP floats on.  The
+// caller's low-res tile replicates the image's last row / column beyond the border, so no tap needs clamping.  `first`: the tile
+// starts at image column 0 (pixels 0, 1 take the first column with weight 0).
+constexpr int MLP = ML + 2;           // low-res row pitch in the grouped kernel: odd, so the 17 rows a wave reads fall in 17 banks
+__device__ __forceinline__ void mask_tile_rows64(const float* lrow, float wy, bool first, float thr, unsigned& lo, unsigned& hi) {
+    float vv[18];
+#pragma unroll
+    for (int j = 0; j < 18; ++j) {
+        const float a = lrow[j], b = lrow[j + MLP];
+        vv[j] = __builtin_fmaf(b - a, wy, a);
+    }
+    unsigned w[2] = {0u, 0u};
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+        for (int k = 31; k >= 0; --k) {
+            const int px = 32 * hf + k;
+            const int jj = ((px - 2) >> 2) + 1;                           // 0 .. 16
+            const float wx = 0.125f + 0.25f * (float)((px + 2) & 3);
+            float v = __builtin_fmaf(vv[jj + 1] - vv[jj], wx, vv[jj]);
+            if (px < 2) v = first ? vv[1] : v;
+            asm("v_cmp_gt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(w[hf]) : "v"(v), "v"(thr) : "vcc");
+        }
+    }
+    lo = w[0]; hi = w[1];
+}
+
+#ifdef VTI_STAMPS   // diagnostic build only: cycles per phase of masks_group_kernel, summed over wave 0 of every block
+__device__ unsigned long long g_mask_acc[8];
+#define MASK_T(i) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
+                       macc[i] += t_ - mprev; mprev = t_; } while (0)
+#else
+#define MASK_T(i) do { } while (0)
 #endif
+
+// ---- nm == 32 (every YOLOv8-seg checkpoint): instances GROUPED per (frame, 64x64 output tile) ----
+// The per-(instance, tile) kernel above fetches the tile's 19 x 19 x 32 prototype footprint once per instance that touches the
+// tile (~23 KB per item: its time was the CU's L1, one access per cycle) and runs the 361 dots on the vector ALU.  Here a work item
+// is a (frame, tile) pair -- a static, frame-major list, no plan kernel, no atomics -- and `coeff x proto` is what it is in the
+// reference: a small GEMM (ops.process_mask: masks_in @ protos.view(c, -1)).  A workgroup
+//   1. lists the frame's instances whose crop box can reach the tile (same rectangle rule as mask_tile_rect; list order =
+//      detection order, built with ballots),
+//   2. loads the prototype footprint ONCE, straight into MFMA operand registers (point = MFMA column; a wave owns 6 of the 23
+//      16-point column tiles; 4 lanes cover a point's 64 contiguous bytes),
+//   3. per group of 16 listed instances: coefficient rows -> the other MFMA operand (fp16 prototypes: c = s * (h + l) with
+//      h = half(c/s), l = half(c/s - h), s a power of two that is 1 unless |c| >= 3e4 -- two 16x16x32 MFMAs per column tile,
+//      products exact, fp32 accumulation, as the split v_dot2 path it replaces; fp32 prototypes: eight exact 16x16x4 steps),
+//      crop, low-res logits -> LDS, then the bilinear 4x upsample + threshold + bit packing of the kernel above, instance by instance.
+// HBM/L2 traffic: prototypes x (19/16)^2 instead of x (instances per tile); the dots leave the vector ALU.
+constexpr int MG = 16;                          // instances per MFMA group
+constexpr int MPTS = ML * ML;                   // 361 low-res points per tile
+constexpr int MTILES = (MPTS + 15) / 16;        // 23 column tiles
+constexpr int MJ = (MTILES + 3) / 4;            // column tiles per wave
+constexpr int MROUND = 64;                      // instances examined per list round (one per lane of wave 0)
+
+template <typename T>
+__global__ __launch_bounds__(256, sizeof(T) == 2 ? 4 : 3) void masks_group_kernel(const float* __restrict__ dets, const int* __restrict__ offsets,
+                                                          const T* __restrict__ proto, int B, int max_det, int Hp, int Wp,
+                                                          int H, int W, int mode, int packing, uint8_t* __restrict__ masks,
+                                                          int capacity) {
+    constexpr bool F16 = sizeof(T) == 2;
+    constexpr int ROW = 6 + 32;
+    typedef typename std::conditional<F16, half8, f32x4>::type opv;      // one MFMA operand register set
+    constexpr int NOP = F16 ? 1 : 2;                                       // fp32: channels 4g..4g+3 and 16+4g..16+4g+3 of lane group g
+    __shared__ uint4 s_co[MROUND][8];          // listed instances' coefficient rows, ready as MFMA operand pieces (128 B each)
+    __shared__ float4 s_box[MROUND];           // ... crop boxes in prototype pixels
+    __shared__ float s_scale[MROUND];
+    __shared__ unsigned short s_list[MROUND];  // ... index inside the round
+    __shared__ int s_n;
+    __shared__ float low[MG][ML][MLP];          // behind the other arrays: the lane-as-row reads start one float before a row
+    const int tid = threadIdx.x, ln = tid & 63, wv = tid >> 6;
+    const int li = ln & 15, lg = ln >> 4;
+    const int tiles_x = (W + MT - 1) / MT, tiles_y = (H + MT - 1) / MT, tiles = tiles_x * tiles_y;
+    const int n = B * tiles;
+    // XCD x (= blockIdx & 7) walks its own contiguous eighth of the frame-major list, round-robin over its workgroups: at any
+    // time an XCD works on about one frame, whose prototypes and dets rows sit in ONE L2
+    const int nx = (int)gridDim.x >> 3, xcd = (int)blockIdx.x & 7, jx = (int)blockIdx.x >> 3;
+    const int per = (n + 7) >> 3;
+    const int it1 = min(n, (xcd + 1) * per);
+    const float wr = (float)((double)Wp / (double)W), hr = (float)((double)Hp / (double)H);       // as in masks_kernel
+    const float sh = (float)Hp / (float)H, sw = (float)Wp / (float)W;
+    const float thr = mode == VTI_MASK_SIGMOID ? 0.5f : 0.0f;
+    // point of this lane in column tile j of this wave: low-res row r (bits 5..9) and column c (0..4) inside the 19 x 19 footprint;
+    // points past 361 (last tile) are (18, 19): the pad column, read for nothing and written to a pad element
+    int prc[MJ];
+#pragma unroll
+    for (int j = 0; j < MJ; ++j) {
+        const int m = wv + 4 * j, pt = 16 * m + li;
+        const bool live = m < MTILES && pt < MPTS;
+        const int r = live ? pt / ML : ML - 1, c = live ? pt - r * ML : ML;
+        prc[j] = (r << 5) | c;
+    }
+#ifdef VTI_STAMPS
+    unsigned long long macc[6] = {0, 0, 0, 0, 0, 0}, mprev, mitems = 0, mpairs = 0;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(mprev)::"memory");
+#endif
+    for (int it = xcd * per + jx; it < it1; it += nx) {
+        const int b = it / tiles, t = it - b * tiles;
+        const int ty = t / tiles_x, tx = t - ty * tiles_x;
+        const int y0 = ty * MT, x0 = tx * MT;
+        const int off_b = offsets[b];
+        const int n_b = min(offsets[b + 1], capacity) - off_b;            // instances of this frame that own a slot
+        if (n_b <= 0) continue;                                            // block-uniform
+        float fy0 = sh * ((float)y0 + 0.5f) - 0.5f; fy0 = fy0 < 0.f ? 0.f : fy0;
+        float fx0 = sw * ((float)x0 + 0.5f) - 0.5f; fx0 = fx0 < 0.f ? 0.f : fx0;
+        const int ly0 = (int)fy0, lx0 = (int)fx0;
+        // ---- prototype footprint -> MFMA operand registers (issued before the list is known: the latency runs under the list build)
+        opv pb[MJ][NOP];
+#pragma unroll
+        for (int j = 0; j < MJ; ++j) {
+            int q = prc[j];
+            asm volatile("" : "+v"(q));                                    // unpack here, every time: hoisted copies cost registers (spills)
+            const int py = ly0 + (q >> 5), px = lx0 + (q & 31);
+            const int pyc = py < Hp ? py : Hp - 1, pxc = px < Wp ? px : Wp - 1;
+            const T* pp = proto + ((size_t)(b * Hp + pyc) * Wp + pxc) * 32;
+            if constexpr (F16) pb[j][0] = *(const half8*)(pp + 8 * lg);
+            else { pb[j][0] = *(const f32x4*)(pp + 4 * lg); pb[j][1] = *(const f32x4*)(pp + 16 + 4 * lg); }
+        }
+        MASK_T(0);                                                         // item decoded, prototype loads issued
+        const int wvy = __builtin_amdgcn_readfirstlane(y0 + 16 * wv);     // first output row of this wave's quarter of the tile
+        const int xg = x0 + ln;
+        int kc0 = xg >= 2 ? (xg - 2) >> 2 : 0;
+        kc0 = kc0 < Wp - 1 ? kc0 : Wp - 1;
+        const int kc1 = kc0 + (kc0 < Wp - 1 ? 1 : 0) - lx0;
+        kc0 -= lx0;
+        const float lx1 = xg >= 2 ? 0.125f + 0.25f * (float)((xg - 2) & 3) : 0.0f;
+        const int rbase = (wvy >> 2) - 1;
+        int ro[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            int rr = rbase + j;
+            rr = rr < 0 ? 0 : (rr > Hp - 1 ? Hp - 1 : rr);
+            ro[j] = (rr - ly0) * MLP;
+        }
+        const int valid = W - x0;
+        const unsigned long long cmask = valid >= 64 ? ~0ull : ((1ull << valid) - 1ull);
+        // lane as a row (bit packing): output row y0 + ln, its upper low-res row and vertical weight; column tap 0 of the tile
+        const int yr = y0 + ln;
+        const int lrow_off = ((yr >= 2 ? (yr - 2) >> 2 : 0) - ly0) * MLP + (tx > 0 ? 0 : -1);
+        const float wy = yr >= 2 ? 0.125f + 0.25f * (float)((yr - 2) & 3) : 0.0f;
+        for (int i0 = 0; i0 < n_b; i0 += MROUND) {
+            // ---- wave 0: the round's instances, one per lane.  The whole 152-byte dets row is loaded before the box is tested (one
+            // memory round trip instead of box -> list -> coefficients); rows of instances that reach the tile go to LDS in detection
+            // order (ballot), already in MFMA operand form.
+            __syncthreads();                                               // previous round / item is done with the shared arrays
+            if (wv == 0) {
+                const int i = i0 + ln;
+                const float* d = dets + ((size_t)b * max_det + (i < n_b ? i : n_b - 1)) * ROW;
+                float2 raw[ROW / 2];                                       // rows are 152 bytes: 8-byte aligned
+#pragma unroll
+                for (int k = 0; k < ROW / 2; ++k) raw[k] = *(const float2*)(d + 2 * k);
+                const float dd[4] = {raw[0].x, raw[0].y, raw[1].x, raw[1].y};
+                int tx0, tx1, ty0, ty1;
+                const bool hit = i < n_b && mask_tile_rect(dd, H, W, tx0, tx1, ty0, ty1) && tx >= tx0 && tx <= tx1 && ty >= ty0 && ty <= ty1;
+                const unsigned long long bal = __builtin_amdgcn_ballot_w64(hit);
+                if (ln == 0) s_n = __builtin_popcountll(bal);
+                if (hit) {
+                    const int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+                    s_list[pos] = (unsigned short)ln;
+                    s_box[pos] = make_float4(dd[0] * wr, dd[1] * hr, dd[2] * wr, dd[3] * hr);     // crop box in prototype pixels (fp32, as torch)
+                    float cf[32];
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) { cf[2 * k] = raw[3 + k].x; cf[2 * k + 1] = raw[3 + k].y; }
+                    float scale = 1.0f;
+                    if constexpr (F16) {
+                        float mx = 0.f;
+#pragma unroll
+                        for (int k = 0; k < 32; ++k) mx = fmaxf(mx, fabsf(cf[k]));
+                        float inv = 1.0f;
+                        if (!(mx < 3.0e4f)) {                              // out of half range: c = 2^e * c', |c'| < 2^14
+                            const int e = (int)((__builtin_bit_cast(unsigned, mx) >> 23) & 255u) - 127 - 13;
+                            const int ec = e < -100 ? -100 : (e > 100 ? 100 : e);
+                            scale = __builtin_bit_cast(float, (unsigned)(ec + 127) << 23);
+                            inv = __builtin_bit_cast(float, (unsigned)(127 - ec) << 23);
+                        }
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {                      // piece q = channels 8q .. 8q+7: high halves, then the residuals
+                            half8 hh, hl;
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) {
+                                const float c = cf[8 * q + k] * inv;
+                                const half_t h = (half_t)c;
+                                hh[k] = h;
+                                hl[k] = (half_t)(c - (float)h);
+                            }
+                            s_co[pos][q] = __builtin_bit_cast(uint4, hh);
+                            s_co[pos][4 + q] = __builtin_bit_cast(uint4, hl);
+                        }
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q)                        // piece q = channels 4q .. 4q+3
+                            s_co[pos][q] = __builtin_bit_cast(uint4, (f32x4){cf[4 * q], cf[4 * q + 1], cf[4 * q + 2], cf[4 * q + 3]});
+                    }
+                    s_scale[pos] = scale;
+                }
+            }
+            __syncthreads();
+            const int nlist = s_n;
+            MASK_T(1);                                                     // list built
+#ifdef VTI_STAMPS
+            ++mitems; mpairs += nlist;
+#endif
+            for (int g0 = 0; g0 < nlist; g0 += MG) {
+                const int ng = min(MG, nlist - g0);
+                // ---- coefficient operand: lane (li, lg) holds instance g0 + li's channels of lane group lg (rows >= ng: stale, unused)
+                opv ca[2];
+                ca[0] = __builtin_bit_cast(opv, s_co[g0 + li][lg]);
+                ca[1] = __builtin_bit_cast(opv, s_co[g0 + li][4 + lg]);
+                // rows 4 lg + r of the MFMA result are instances g0 + 4 lg + r: their boxes and scales
+                float4 rb[4];
+                float rs[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int u = 4 * lg + r;
+                    rb[r] = s_box[g0 + u];
+                    rs[r] = s_scale[g0 + u];
+                }
+#pragma unroll
+                for (int j = 0; j < MJ; ++j) {
+                    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if constexpr (F16) {
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ca[0], pb[j][0], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ca[1], pb[j][0], acc, 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 2; ++q)
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[q][k], pb[j][q][k], acc, 0, 0, 0);
+                    }
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = F16 ? acc[r] * rs[r] : acc[r];
+                    if (mode == VTI_MASK_SIGMOID) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = 1.0f / (1.0f + expf(-v[r]));
+                    }
+                    // branch-free stores: rows >= ng of `low` are never read, points that do not exist write their row's pad element
+                    int q = prc[j];
+                    asm volatile("" : "+v"(q));
+                    // points beyond the image's last row / column take that row's / column's value (they were loaded from the clamped
+                    // address): the border replication of F.interpolate's taps, done once here instead of in every tap
+                    const int pr = q >> 5, pc = q & 31, py = min(ly0 + pr, Hp - 1), px = min(lx0 + pc, Wp - 1);
+                    const float pfc = (float)px, pfr = (float)py;
+                    const int pla = pr * MLP + pc;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const bool inb = pfc >= rb[r].x && pfc < rb[r].z && pfr >= rb[r].y && pfr < rb[r].w;
+                        (&low[4 * lg + r][0][0])[pla] = inb ? v[r] : 0.f;
+                    }
+                }
+                MASK_T(2);                                                 // coefficients loaded, MFMAs, low-res tiles written
+                __syncthreads();
+                MASK_T(3);
+                // ---- upsample + threshold + store
+                if (packing != VTI_PACK_U8) {
+                    // bits: a wave takes every fourth listed instance and produces its whole tile, a lane is a row (mask_tile_rows64)
+                    for (int u = wv; u < ng; u += 4) {
+                        const int slot = off_b + i0 + (int)s_list[g0 + u];
+                        unsigned lo, hi;
+                        mask_tile_rows64(&low[u][0][0] + lrow_off, wy, tx == 0, thr, lo, hi);
+                        lo &= (unsigned)cmask; hi &= (unsigned)(cmask >> 32);
+                        if (yr < H) {
+                            unsigned* o = (unsigned*)(masks + ((size_t)slot * H + yr) * (W >> 3) + (x0 >> 3));
+                            if (valid >= 64 && !(W & 63)) *(uint2*)o = make_uint2(lo, hi);      // rows of W/8 bytes with W % 64 == 0: 8-byte aligned
+                            else {
+                                o[0] = lo;
+                                if (valid >= 64) o[1] = hi;
+                            }
+                        }
+                    }
+                } else if (wvy < H) {
+                    // bytes: the wave owns 16 rows of the tile, a lane is a column (mask_rows16: coalesced byte stores)
+                    for (int u = 0; u < ng; ++u) {
+                        const int slot = off_b + i0 + (int)s_list[g0 + u];
+                        unsigned lo = 0u, hi = 0u;
+                        mask_rows16<true>(&low[u][0][0], ro, kc0, kc1, lx1, wvy == 0, thr, lo, hi, masks + (size_t)slot * H * W, W, H, wvy, xg);
+                    }
+                }
+                MASK_T(4);                                                 // this wave's bands upsampled and stored
+                if (g0 + MG < nlist) __syncthreads();                      // the next group overwrites `low`
+                MASK_T(5);
+            }
+        }
     }
 #ifdef VTI_STAMPS
     if (tid == 0) {
         for (int i = 0; i < 6; ++i) atomicAdd(&g_mask_acc[i], macc[i]);
-        atomicAdd(&g_mask_acc[6], mitems);
+        atomicAdd(&g_mask_acc[6], mitems); atomicAdd(&g_mask_acc[7], mpairs);
     }
 #endif
 }
 
 size_t masks_workspace_bytes(int capacity, int H, int W) {
     const size_t tiles = (size_t)((H + MT - 1) / MT) * ((W + MT - 1) / MT);
-    return 256 + ((((size_t)capacity * tiles * 8) + 255) & ~(size_t)255) + (size_t)capacity * 128;   // nitems | items | split coefficients
+    return 256 + ((((size_t)capacity * tiles * 8) + 255) & ~(size_t)255);      // nitems | items (the nm != 32 kernel's work list)
 }
 
 hipError_t launch_masks(int dtype, const float* dets, const int* counts, const void* proto, int B, int max_det, int nm,
@@ -815,8 +1033,6 @@ hipError_t launch_masks(int dtype, const float* dets, const int* counts, const v
     if (Hp * 4 != H || Wp * 4 != W || nm > 64) return hipErrorInvalidValue;   // tile geometry assumes stride-4 prototypes
     int* nitems = (int*)ws;
     int2* items = (int2*)((char*)ws + 256);
-    const size_t tiles = (size_t)((H + MT - 1) / MT) * ((W + MT - 1) / MT);
-    unsigned* csplit = (dtype == VTI_F16 && nm == 32) ? (unsigned*)((char*)ws + 256 + ((((size_t)capacity * tiles * 8) + 255) & ~(size_t)255)) : nullptr;
     if (max_det > 65535 || B > 32767 || H > 64 * MT || W > 64 * MT || capacity > (1 << 19)) return hipErrorInvalidValue;    // item record fields
     hipLaunchKernelGGL(mask_offsets_kernel, dim3(1), dim3(256), (size_t)(B + 1) * sizeof(int), st, counts, B, max_det, offsets, nitems);
     if (capacity <= 0) return hipGetLastError();
@@ -824,8 +1040,6 @@ hipError_t launch_masks(int dtype, const float* dets, const int* counts, const v
     if ((slot_bytes & 15) || ((uintptr_t)masks & 15)) return hipErrorInvalidValue;
     // (running the clear on a side stream next to the plan was tried: the two event hops cost more than the 13 us they hide)
     hipLaunchKernelGGL(mask_clear_kernel, dim3(capacity), dim3(256), 0, st, offsets, B, (int)slot_bytes, capacity, masks);
-    hipLaunchKernelGGL(mask_plan_kernel, dim3((capacity + 255) / 256), dim3(256), 0, st, dets, offsets, B, max_det, 6 + nm, H, W,
-                       capacity, items, nitems, csplit);
     // persistent blocks walk the work list: exactly as many as are resident at once (a second round of late blocks would run
     // on a mostly empty chip), a multiple of 8 for the per-XCD partition
     static int per_cu_dev[kMaxDevices][4] = {};
@@ -833,30 +1047,43 @@ hipError_t launch_masks(int dtype, const float* dets, const int* counts, const v
     const int kidx = (dtype == VTI_F16 ? 0 : 2) + (nm == 32 ? 0 : 1);
     if (!per_cu[kidx]) {
         int nb = 0;
-        const void* fn = dtype == VTI_F16 ? (nm == 32 ? (const void*)masks_kernel<half_t, 32> : (const void*)masks_kernel<half_t, 0>)
-                                          : (nm == 32 ? (const void*)masks_kernel<float, 32> : (const void*)masks_kernel<float, 0>);
+        const void* fn = dtype == VTI_F16 ? (nm == 32 ? (const void*)masks_group_kernel<half_t> : (const void*)masks_kernel<half_t>)
+                                          : (nm == 32 ? (const void*)masks_group_kernel<float> : (const void*)masks_kernel<float>);
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 256, 0) != hipSuccess || nb < 1) nb = 4;
         per_cu[kidx] = nb > 8 ? 8 : nb;
     }
     const int grid = 256 * per_cu[kidx];
-#define VTI_MASKS(TT, NMV) hipLaunchKernelGGL((masks_kernel<TT, NMV>), dim3(grid), dim3(256), 0, st, dets, offsets, (const TT*)proto, \
-                                                B, max_det, nm, Hp, Wp, H, W, mode, packing, masks, items, nitems, csplit)
-    if (dtype == VTI_F16) { if (nm == 32) VTI_MASKS(half_t, 32); else VTI_MASKS(half_t, 0); }
-    else { if (nm == 32) VTI_MASKS(float, 32); else VTI_MASKS(float, 0); }
-#undef VTI_MASKS
+    if (nm == 32) {
+        // the (frame, tile) list is static: no plan, no work-list memory
+        if (dtype == VTI_F16)
+            hipLaunchKernelGGL(masks_group_kernel<half_t>, dim3(grid), dim3(256), 0, st, dets, offsets, (const half_t*)proto, B, max_det, Hp, Wp,
+                               H, W, mode, packing, masks, capacity);
+        else
+            hipLaunchKernelGGL(masks_group_kernel<float>, dim3(grid), dim3(256), 0, st, dets, offsets, (const float*)proto, B, max_det, Hp, Wp,
+                               H, W, mode, packing, masks, capacity);
 #ifdef VTI_STAMPS
-    {
-        (void)hipStreamSynchronize(st);
-        static int calls = 0;
-        if (++calls == 3) {
-            unsigned long long h[8];
-            (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_mask_acc), sizeof h);
-            const char* nm_[6] = {"decode item", "barrier 1", "box + issue loads", "dots -> LDS", "barrier 2", "upsample + store"};
-            fprintf(stderr, "[mask stamps] %llu items over %d calls (wave 0 of each block; 100 MHz ticks per item)\n", h[6], calls);
-            for (int i = 0; i < 6; ++i) fprintf(stderr, "[mask stamps] %-18s %8.1f\n", nm_[i], (double)h[i] / (double)h[6]);
+        {
+            (void)hipStreamSynchronize(st);
+            static int calls = 0;
+            if (++calls == 3) {
+                unsigned long long h[8];
+                (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_mask_acc), sizeof h);
+                const char* nm_[6] = {"decode + issue protos", "list build", "coeffs + MFMA + low", "barrier", "upsample + store", "barrier (next group)"};
+                fprintf(stderr, "[mask stamps] %llu (frame, tile) items, %llu (instance, tile) pairs over %d calls (wave 0 of each block; s_memtime ticks per item)\n", h[6], h[7], calls);
+                for (int i = 0; i < 6; ++i) fprintf(stderr, "[mask stamps] %-22s %9.1f\n", nm_[i], (double)h[i] / (double)h[6]);
+            }
         }
-    }
 #endif
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL(mask_plan_kernel, dim3((capacity + 255) / 256), dim3(256), 0, st, dets, offsets, B, max_det, 6 + nm, H, W,
+                       capacity, items, nitems);
+    if (dtype == VTI_F16)
+        hipLaunchKernelGGL(masks_kernel<half_t>, dim3(grid), dim3(256), 0, st, dets, offsets, (const half_t*)proto, B, max_det, nm, Hp, Wp,
+                           H, W, mode, packing, masks, items, nitems);
+    else
+        hipLaunchKernelGGL(masks_kernel<float>, dim3(grid), dim3(256), 0, st, dets, offsets, (const float*)proto, B, max_det, nm, Hp, Wp,
+                           H, W, mode, packing, masks, items, nitems);
     return hipGetLastError();
 }
 
