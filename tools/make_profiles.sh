@@ -26,7 +26,7 @@ out = "gpurun_out/profiles"
 def fam(n):
     if any(k in n for k in ("conv_kernel", "stem_kernel", "conv3_pk", "conv1_pk", "stem_l1", "bneck_pk", "convfold_kernel")):
         return "conv family (conv3_pk + conv1_pk + bneck_pk + conv_kernel + stem_l1_kernel)"
-    for k in ("decode_kernel", "masks_kernel", "nms_kernel", "nms_scan_kernel", "mask_plan_kernel", "mask_clear_kernel", "mask_offsets_kernel",
+    for k in ("decode_kernel", "masks_group_kernel", "masks_kernel", "nms_kernel", "nms_scan_kernel", "mask_plan_kernel", "mask_clear_kernel", "mask_offsets_kernel",
               "sppf_pool", "upsample2x", "scale_boxes", "letterbox"):
         if k in n: return k
     return None
