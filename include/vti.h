@@ -130,6 +130,15 @@ int32_t vti_forward(vti_ctx* ctx, const uint8_t* dev_input, int32_t B, int32_t s
 /* U6 non_max_suppression (class-aware unless agnostic), torchvision.ops.nms semantics. */
 int32_t vti_nms(vti_ctx* ctx, const float* dev_pred, int32_t B, float conf, double iou,
                 int32_t max_det, int32_t agnostic, float* dev_dets, int32_t* dev_counts, void* stream);
+/* U5 -> U6 hand-over without re-reading the class scores: vti_forward_scored also writes, for every anchor, the pair (best class
+ * score, index of the first class that has it, as a float) into dev_anchor_best (f32 [B, A, 2]) -- from the class towers' epilogue,
+ * where the scores are in registers -- and vti_nms_scored takes its candidates (score > conf) from those 8 bytes per anchor instead of
+ * scanning nc scores per anchor of dev_pred (Ultralytics: x[:, 4:4+nc].amax(1) > conf_thres, the first thing non_max_suppression
+ * does).  Same detections as vti_forward + vti_nms, bit for bit; the pairs must belong to the dev_pred they are passed with. */
+int32_t vti_forward_scored(vti_ctx* ctx, const uint8_t* dev_input, int32_t B, int32_t swap_rb,
+                           float* dev_pred, void* dev_proto, float* dev_anchor_best, void* stream);
+int32_t vti_nms_scored(vti_ctx* ctx, const float* dev_pred, const float* dev_anchor_best, int32_t B, float conf, double iou,
+                       int32_t max_det, int32_t agnostic, float* dev_dets, int32_t* dev_counts, void* stream);
 /* U7 process_mask(upsample=True) + threshold.  Writes slots [0, min(offsets[B], capacity)) of dev_masks completely; slots
  * beyond that are left untouched (no whole-buffer memset: the cost follows the number of instances, not the capacity). */
 int32_t vti_masks(vti_ctx* ctx, const float* dev_dets, const int32_t* dev_counts, const void* dev_proto,
@@ -138,7 +147,8 @@ int32_t vti_masks(vti_ctx* ctx, const float* dev_dets, const int32_t* dev_counts
 /* U8 scale_boxes + clip: letterboxed px -> frame px, writes f32 [B,max_det,4]. */
 int32_t vti_scale_boxes(vti_ctx* ctx, const float* dev_dets, const int32_t* dev_counts, int32_t B,
                         int32_t max_det, int32_t H0, int32_t W0, float* dev_xyxy, void* stream);
-/* All of the above on one stream.  dev_input_scratch (u8 [B,H,W,3]) may be NULL when H0xW0 == HxW. */
+/* All of the above on one stream (the scored pair of entry points, with the pairs in the workspace).  dev_input_scratch
+ * (u8 [B,H,W,3]) may be NULL when H0xW0 == HxW. */
 int32_t vti_predict(vti_ctx* ctx, const uint8_t* dev_frames, int32_t B, int32_t H0, int32_t W0,
                     int32_t swap_rb, float conf, double iou, int32_t max_det, int32_t agnostic,
                     int32_t mask_mode, int32_t packing, uint8_t* dev_input_scratch,

@@ -54,6 +54,8 @@ SIGNATURES = {
     "vti_letterbox": (_I32, [_P, _P, _I32, _I32, _I32, _P, _P]),
     "vti_forward": (_I32, [_P, _P, _I32, _I32, _P, _P, _P]),
     "vti_nms": (_I32, [_P, _P, _I32, _F, _D, _I32, _I32, _P, _P, _P]),
+    "vti_forward_scored": (_I32, [_P, _P, _I32, _I32, _P, _P, _P, _P]),
+    "vti_nms_scored": (_I32, [_P, _P, _P, _I32, _F, _D, _I32, _I32, _P, _P, _P]),
     "vti_masks": (_I32, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _P, _I32, _P, _P]),
     "vti_scale_boxes": (_I32, [_P, _P, _P, _I32, _I32, _I32, _I32, _P, _P]),
     "vti_predict": (_I32, [_P, _P, _I32, _I32, _I32, _I32, _F, _D, _I32, _I32, _I32, _I32,

@@ -415,11 +415,18 @@ __device__ __forceinline__ void conv_stage2(const ConvParams& p, f32x4 (&acc)[MR
             return;
         }
     }
+    const bool want_best = p.act2 == 2 && p.best != nullptr;            // wave-uniform
 #pragma unroll
     for (int m = 0; m < MREP; ++m) {
-        if (!pvalid[m]) continue;
         // out2_bstride = pixels per frame of the destination: Hout*Wout, or the anchor count when the towers write into pred
-        const size_t o0 = ((size_t)b * p.out2_bstride + (size_t)opy[m] * OW + opx[m]) * p.out2_ld + p.out2_coff;
+        const size_t pix = (size_t)b * p.out2_bstride + (size_t)opy[m] * OW + opx[m];
+        const size_t o0 = pix * p.out2_ld + p.out2_coff;
+        // (max score, first class that has it) of this pixel, for the NMS candidate filter (post.hip: nms_kernel reads these 8 bytes
+        // instead of the nc scores): strict > over the lane's ascending channels, then the lane groups' partial results with ties going
+        // to the lower class -- the same pair nms_scan_kernel derives from the stored row.  No pvalid branch around the shuffles.
+        float bv = -INFINITY;
+        int bc = 0x7fffffff;
+        if (!want_best && !pvalid[m]) continue;
 #pragma unroll
         for (int n = 0; n < NREP2; ++n) {
             const int cout0 = crun2 + cstep2 * n;
@@ -432,7 +439,13 @@ __device__ __forceinline__ void conv_stage2(const ConvParams& p, f32x4 (&acc)[MR
                     if constexpr (FAST) v[j] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v[j] * -1.4426950408889634f));
                     else v[j] = 1.0f / (1.0f + expf(-v[j]));
                 }
+                if (want_best) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (cout0 + j < p.Cout2 && v[j] > bv) { bv = v[j]; bc = cout0 + j; }
+                }
             }
+            if (!pvalid[m]) continue;
             const size_t o = o0 + cout0;
             if (p.scalar_store2) {
 #pragma unroll
@@ -450,6 +463,15 @@ __device__ __forceinline__ void conv_stage2(const ConvParams& p, f32x4 (&acc)[MR
                 for (int j = 0; j < 4; ++j) hv[j] = (half_t)v[j];
                 *(half4*)((half_t*)p.out2 + o) = hv;
             }
+        }
+        if (want_best) {
+#pragma unroll
+            for (int o = 16; o <= 32; o <<= 1) {
+                const float ob = __shfl_xor(bv, o);
+                const int oc = __shfl_xor(bc, o);
+                if (ob > bv || (ob == bv && oc < bc)) { bv = ob; bc = oc; }
+            }
+            if (lane < 16 && pvalid[m]) *(float2*)(p.best + pix * 2) = make_float2(bv, (float)(bc == 0x7fffffff ? 0 : bc));
         }
     }
 }

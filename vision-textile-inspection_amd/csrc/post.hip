@@ -131,12 +131,15 @@ static NmsWsLayout nms_layout(int A) {
     l.per_frame = off;
     return l;
 }
-size_t nms_workspace_bytes(int B, int A) { return nms_layout(A).per_frame * (size_t)B + align256((size_t)B * 4); }
+size_t nms_workspace_bytes(int B, int A) { return nms_layout(A).per_frame * (size_t)B + align256((size_t)B * 4) + align256((size_t)B * A * 8); }
+float* nms_workspace_best(void* ws, int B, int A) { return (float*)((char*)ws + nms_layout(A).per_frame * (size_t)B + align256((size_t)B * 4)); }
 
 // Stage 1 (whole chip): best class score per anchor (first maximal index); anchors above `conf` are
 // appended to the frame's key list.  Arrival order is arbitrary -- the sort below restores the order.
+// With `best_out` the kernel only records the (score, class) pair of every anchor -- launch_anchor_best: the pairs a plan without
+// fused class towers cannot write from its epilogue.
 __global__ __launch_bounds__(256) void nms_scan_kernel(const float* __restrict__ pred, int A, int nc, int nm, float conf,
-                                                       char* ws, NmsWsLayout L, int* __restrict__ ncand) {
+                                                       char* ws, NmsWsLayout L, int* __restrict__ ncand, float* __restrict__ best_out) {
     const int b = blockIdx.y;
     const int no = 4 + nc + nm;
     float best;
@@ -190,6 +193,10 @@ __global__ __launch_bounds__(256) void nms_scan_kernel(const float* __restrict__
             const float v = P[4 + c];
             if (v > best) { best = v; j = c; }
         }
+    }
+    if (best_out) {
+        *(float2*)(best_out + ((size_t)b * A + a) * 2) = make_float2(best, (float)(j == 0x7fffffff ? 0 : j));
+        return;
     }
     if (best > conf) {
         char* wsb = ws + (size_t)b * L.per_frame;
@@ -406,7 +413,8 @@ __device__ __forceinline__ void nms_body(const float* __restrict__ P, int A, int
 __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const float* __restrict__ pred, int A, int nc, int nm,
                                                           float conf, double iou, int max_det, int agnostic,
                                                           float* __restrict__ dets, int* __restrict__ counts,
-                                                          char* ws, NmsWsLayout L, const int* __restrict__ ncand) {
+                                                          char* ws, NmsWsLayout L, int* __restrict__ ncand,
+                                                          const float* __restrict__ best) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     unsigned long long* lds_keys = (unsigned long long*)smem;             // NMS_LDS_KEYS entries
     f32x4* lds_boxes = (f32x4*)(smem + NMS_LDS_KEYS * 8);                 // NMS_LDS_BOX entries
@@ -421,7 +429,32 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const float* __restric
     unsigned long long* g_keys = (unsigned long long*)(wsb + L.keys);
     const int* cls_of = (const int*)(wsb + L.cls);
     float* D = dets + (size_t)b * max_det * (6 + nm);
-    const int n = ncand[b];
+    __shared__ int s_cnt;
+    if (best) {
+        // Stage 1 here, from the per-anchor (max score, class) pairs written beside pred (8 bytes per anchor instead of nc scores):
+        // anchors above `conf` go to the frame's key list.  Arrival order is arbitrary -- the sort restores the order.
+        if (tid == 0) s_cnt = 0;
+        __syncthreads();
+        const float2* bp = (const float2*)best + (size_t)b * A;
+        int* cls_w = (int*)(wsb + L.cls);
+        for (int a0 = 0; a0 < A; a0 += 4 * NMS_THREADS) {
+            float2 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int a = a0 + tid + u * NMS_THREADS; v[u] = bp[a < A ? a : A - 1]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int a = a0 + tid + u * NMS_THREADS;
+                if (a < A && v[u].x > conf) {
+                    const int idx = atomicAdd(&s_cnt, 1);
+                    g_keys[idx] = ((unsigned long long)(~__float_as_uint(v[u].x)) << 32) | (unsigned)a;
+                    cls_w[a] = (int)v[u].y;
+                }
+            }
+        }
+        __syncthreads();                          // the block's global writes are visible to the block behind the barrier
+        if (tid == 0) ncand[b] = s_cnt;
+    }
+    const int n = best ? s_cnt : ncand[b];
     if (n == 0) {
         if (tid == 0) counts[b] = 0;
         for (int i = tid; i < max_det * (6 + nm); i += NMS_THREADS) D[i] = 0.f;
@@ -441,7 +474,15 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const float* __restric
     }
 }
 
-hipError_t launch_nms(const float* pred, int B, int A, int nc, int nm, float conf, double iou, int max_det,
+hipError_t launch_anchor_best(const float* pred, int B, int A, int nc, int nm, float* best, hipStream_t st) {
+    if (B == 0) return hipSuccess;
+    const int apb = (((4 + nc + nm) | nc) & 3) == 0 ? 64 : 256;
+    hipLaunchKernelGGL(nms_scan_kernel, dim3((A + apb - 1) / apb, B), dim3(256), 0, st, pred, A, nc, nm, 0.0f, (char*)nullptr, nms_layout(A),
+                       (int*)nullptr, best);
+    return hipGetLastError();
+}
+
+hipError_t launch_nms(const float* pred, const float* best, int B, int A, int nc, int nm, float conf, double iou, int max_det,
                       int agnostic, float* dets, int* counts, void* ws, hipStream_t st) {
     if (B == 0) return hipSuccess;
     const size_t lds = (size_t)NMS_LDS_KEYS * 8 + (size_t)NMS_LDS_BOX * 32 + (((size_t)A + 15) & ~(size_t)15);
@@ -455,12 +496,14 @@ hipError_t launch_nms(const float* pred, int B, int A, int nc, int nm, float con
     }
     const NmsWsLayout L = nms_layout(A);
     int* ncand = (int*)((char*)ws + L.per_frame * (size_t)B);
-    hipError_t e = hipMemsetAsync(ncand, 0, sizeof(int) * (size_t)B, st);
-    if (e != hipSuccess) return e;
-    const int apb = (((4 + nc + nm) | nc) & 3) == 0 ? 64 : 256;        // anchors per block: quad-per-anchor / lane-per-anchor
-    hipLaunchKernelGGL(nms_scan_kernel, dim3((A + apb - 1) / apb, B), dim3(256), 0, st, pred, A, nc, nm, conf, (char*)ws, L, ncand);
+    if (!best) {
+        hipError_t e = hipMemsetAsync(ncand, 0, sizeof(int) * (size_t)B, st);
+        if (e != hipSuccess) return e;
+        const int apb = (((4 + nc + nm) | nc) & 3) == 0 ? 64 : 256;        // anchors per block: quad-per-anchor / lane-per-anchor
+        hipLaunchKernelGGL(nms_scan_kernel, dim3((A + apb - 1) / apb, B), dim3(256), 0, st, pred, A, nc, nm, conf, (char*)ws, L, ncand, (float*)nullptr);
+    }
     hipLaunchKernelGGL(nms_kernel, dim3(B), dim3(NMS_THREADS), lds, st, pred, A, nc, nm, conf, iou, max_det, agnostic,
-                       dets, counts, (char*)ws, L, ncand);
+                       dets, counts, (char*)ws, L, ncand, best);
 #ifdef VTI_STAMPS
     {
         (void)hipStreamSynchronize(st);

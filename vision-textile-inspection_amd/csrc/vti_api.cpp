@@ -295,7 +295,19 @@ static void fill_conv_params(int conv_elem_size, ConvParams& p, const ConvRow& r
     }
 }
 
+static int32_t forward_impl(vti_ctx* c, const uint8_t* input, int32_t B, int32_t swap_rb, float* pred, void* proto, float* best, void* stream);
+
 int32_t vti_forward(vti_ctx* c, const uint8_t* input, int32_t B, int32_t swap_rb, float* pred, void* proto, void* stream) {
+    return forward_impl(c, input, B, swap_rb, pred, proto, nullptr, stream);
+}
+
+int32_t vti_forward_scored(vti_ctx* c, const uint8_t* input, int32_t B, int32_t swap_rb, float* pred, void* proto, float* anchor_best,
+                           void* stream) {
+    if (!anchor_best) return fail(c, VTI_ERR_ARG, "vti_forward_scored: null pointer");
+    return forward_impl(c, input, B, swap_rb, pred, proto, anchor_best, stream);
+}
+
+static int32_t forward_impl(vti_ctx* c, const uint8_t* input, int32_t B, int32_t swap_rb, float* pred, void* proto, float* best, void* stream) {
     int32_t rc = check_ready(c, B, "vti_forward");
     if (rc) return rc;
     if (!input || !pred || !proto) return fail(c, VTI_ERR_ARG, "vti_forward: null pointer");
@@ -435,6 +447,7 @@ int32_t vti_forward(vti_ctx* c, const uint8_t* input, int32_t B, int32_t swap_rb
                     p.act2 = op.pred_mode == 2 ? 2 : op.pred_mode == 3 ? 3 : 0;
                     p.dfl_stride = (float)op.dfl_stride;
                     p.scalar_store2 = (g.gemm_n2 % 4 || no % 4 || op.pred_cbase % 4) ? 1 : 0;
+                    p.best = (op.pred_mode == 2 && best) ? best + (size_t)op.pred_a0 * 2 : nullptr;     // class towers: (max, class) per anchor
                 }
             }
             if (op.pair >= 0) {         // fused Bottleneck: second conv's weights; p.out / p.res already are the second conv's views
@@ -522,8 +535,23 @@ int32_t vti_forward(vti_ctx* c, const uint8_t* input, int32_t B, int32_t swap_rb
         }
         }
     }
+    // a plan whose class towers do not write pred themselves (VTI_NO_SCATTER ...) derives the pairs from the finished rows
+    if (best && !P.pred_scatter)
+        VTI_HIP(c, launch_anchor_best(pred, B, P.num_anchors, P.desc.nc, P.desc.nm, best, main_st), "anchor pairs");
     c->last_input = input;
     c->last_proto = proto;
+    return VTI_OK;
+}
+
+int32_t vti_nms_scored(vti_ctx* c, const float* pred, const float* anchor_best, int32_t B, float conf, double iou, int32_t max_det,
+                       int32_t agnostic, float* dets, int32_t* counts, void* stream) {
+    if (!c) return VTI_ERR_ARG;
+    if (B < 0 || B > c->plan.desc.max_batch) return fail(c, VTI_ERR_ARG, "vti_nms_scored: B out of range");
+    if (!c->ws) return fail(c, VTI_ERR_STATE, "vti_nms_scored: workspace not set");
+    if (!pred || !anchor_best || !dets || !counts || max_det < 1) return fail(c, VTI_ERR_ARG, "vti_nms_scored: bad argument");
+    if (int32_t drc = check_device(c, "vti_nms_scored")) return drc;
+    VTI_HIP(c, launch_nms(pred, anchor_best, B, c->plan.num_anchors, c->plan.desc.nc, c->plan.desc.nm, conf, iou, max_det, agnostic,
+                          dets, counts, c->ws + c->act_bytes, (hipStream_t)stream), "nms kernel");
     return VTI_OK;
 }
 
@@ -534,7 +562,7 @@ int32_t vti_nms(vti_ctx* c, const float* pred, int32_t B, float conf, double iou
     if (!c->ws) return fail(c, VTI_ERR_STATE, "vti_nms: workspace not set");
     if (!pred || !dets || !counts || max_det < 1) return fail(c, VTI_ERR_ARG, "vti_nms: bad argument");
     if (int32_t drc = check_device(c, "vti_nms")) return drc;
-    VTI_HIP(c, launch_nms(pred, B, c->plan.num_anchors, c->plan.desc.nc, c->plan.desc.nm, conf, iou, max_det, agnostic,
+    VTI_HIP(c, launch_nms(pred, nullptr, B, c->plan.num_anchors, c->plan.desc.nc, c->plan.desc.nm, conf, iou, max_det, agnostic,
                           dets, counts, c->ws + c->act_bytes, (hipStream_t)stream), "nms kernel");
     return VTI_OK;
 }
@@ -581,8 +609,11 @@ int32_t vti_predict(vti_ctx* c, const uint8_t* frames, int32_t B, int32_t H0, in
         if (rc) return rc;
         input = input_scratch;
     }
-    if ((rc = vti_forward(c, input, B, swap_rb, pred, proto, stream))) return rc;
-    if ((rc = vti_nms(c, pred, B, conf, iou, max_det, agnostic, dets, counts, stream))) return rc;
+    // the (max score, class) pairs travel from the class towers to the NMS filter through the library's own workspace
+    float* best = c->ws ? nms_workspace_best(c->ws + c->act_bytes, d.max_batch, c->plan.num_anchors) : nullptr;
+    if (!best) return fail(c, VTI_ERR_STATE, "vti_predict: workspace not set");
+    if ((rc = vti_forward_scored(c, input, B, swap_rb, pred, proto, best, stream))) return rc;
+    if ((rc = vti_nms_scored(c, pred, best, B, conf, iou, max_det, agnostic, dets, counts, stream))) return rc;
     if ((rc = vti_masks(c, dets, counts, proto, B, max_det, mask_mode, packing, masks, capacity, offsets, stream))) return rc;
     if (xyxy && (rc = vti_scale_boxes(c, dets, counts, B, max_det, H0, W0, xyxy, stream))) return rc;
     return VTI_OK;

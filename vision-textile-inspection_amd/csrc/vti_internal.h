@@ -120,6 +120,7 @@ struct ConvParams {
     // fused 1x1 second stage: out2 = act2(W2 . silu(conv + bias) + bias2), never touching HBM in between
     const void* w2; const float* bias2; void* out2;
     int Cout2, ntiles2, out2_ld, out2_coff, act2 /*0 none, 1 SiLU, 2 sigmoid, 3 DFL + dist2bbox*/, out2_f32, scalar_store2, nat2, out2_bstride;
+    float* best;      // act2 == 2 (class scores into pred): also (max score, its first class) per anchor -> best[(b * out2_bstride + pixel) * 2], or null
     float dfl_stride;
     // persistent kernel (conv_pk.hip): tile count, workgroups along x, XCD-contiguous tile ranges, tensor sizes
     int pk, pk_tiles, pk_wgs, pk_xcd, pk_depth, pk_wstat;
@@ -200,8 +201,12 @@ hipError_t launch_debug_nchw(int elem_is_f32, const void* src, int B, int H, int
 hipError_t launch_letterbox(const uint8_t* frames, int B, int H0, int W0, uint8_t* out, int H, int W,
                             int new_h, int new_w, int top, int left, hipStream_t st);
 size_t nms_workspace_bytes(int B, int A);
-hipError_t launch_nms(const float* pred, int B, int A, int nc, int nm, float conf, double iou, int max_det,
+// `best`: optional [B, A, 2] floats (max class score, its first class index as a float) that the producer of `pred` wrote beside it
+// (vti_forward_scored): the candidate filter then reads 8 bytes per anchor instead of the nc class scores
+hipError_t launch_nms(const float* pred, const float* best, int B, int A, int nc, int nm, float conf, double iou, int max_det,
                       int agnostic, float* dets, int* counts, void* ws, hipStream_t st);
+hipError_t launch_anchor_best(const float* pred, int B, int A, int nc, int nm, float* best, hipStream_t st);   // the same pairs from pred itself
+float* nms_workspace_best(void* ws, int B, int A);       // [B, A, 2] floats at the end of the NMS workspace (vti_predict's own pair buffer)
 hipError_t launch_masks(int dtype, const float* dets, const int* counts, const void* proto, int B, int max_det,
                         int nm, int Hp, int Wp, int H, int W, int mode, int packing, uint8_t* masks,
                         int capacity, int* offsets, void* ws, hipStream_t st);

@@ -124,9 +124,10 @@ class Engine:
         pa = pred.transpose(1, 2)
         return pa if pa.is_contiguous() else pa.contiguous()
 
-    def forward(self, inp, swap_rb=True, pred=None, proto=None):
+    def forward(self, inp, swap_rb=True, pred=None, proto=None, best=None):
         """inp: u8 [B,H,W,3] letterboxed -> pred f32 [B,4+nc+nm,A] (a view of anchor-major memory, see alloc_pred),
-        proto T [B,H/4,W/4,nm] (NHWC)."""
+        proto T [B,H/4,W/4,nm] (NHWC).  best: optional f32 [B,A,2] that receives (best class score, its class) per anchor
+        for nms(best=...) -- vti_forward_scored."""
         self._check_input(inp, (self.H, self.W))
         B = inp.shape[0]
         if pred is None:
@@ -135,19 +136,36 @@ class Engine:
             raise ValueError("pred must come from Engine.alloc_pred / alloc_outputs (anchor-major memory)")
         if proto is None:
             proto = torch.empty((B, self.H // 4, self.W // 4, self.nm), dtype=self.torch_dtype, device=inp.device)
-        check(self._ctx, lib().vti_forward(self._ctx, _ptr(inp), B, int(bool(swap_rb)), _ptr(pred), _ptr(proto), _stream()))
+        if best is None:
+            check(self._ctx, lib().vti_forward(self._ctx, _ptr(inp), B, int(bool(swap_rb)), _ptr(pred), _ptr(proto), _stream()))
+        else:
+            self._check_best(best, B)
+            check(self._ctx, lib().vti_forward_scored(self._ctx, _ptr(inp), B, int(bool(swap_rb)), _ptr(pred), _ptr(proto), _ptr(best), _stream()))
         return pred, proto
 
-    def nms(self, pred, conf=0.25, iou=0.7, max_det=300, agnostic=False, dets=None, counts=None):
-        """pred: [B, 4+nc+nm, A] (any layout; tensors from forward()/alloc_pred are used in place)."""
+    def alloc_best(self, B, device=None):
+        return torch.empty((B, self.num_anchors, 2), dtype=torch.float32, device=device or self.device)
+
+    def _check_best(self, best, B):
+        if best.dtype != torch.float32 or tuple(best.shape) != (B, self.num_anchors, 2) or not best.is_contiguous():
+            raise ValueError("best must be a contiguous f32 [B, A, 2] tensor (Engine.alloc_best)")
+
+    def nms(self, pred, conf=0.25, iou=0.7, max_det=300, agnostic=False, dets=None, counts=None, best=None):
+        """pred: [B, 4+nc+nm, A] (any layout; tensors from forward()/alloc_pred are used in place).  best: the pairs forward(best=...)
+        wrote for THIS pred (vti_nms_scored: the candidate filter reads them instead of the class scores)."""
         pred = self._anchor_major(pred)
         B = pred.shape[0]
         if dets is None:
             dets = torch.empty((B, max_det, 6 + self.nm), dtype=torch.float32, device=pred.device)
         if counts is None:
             counts = torch.empty((B,), dtype=torch.int32, device=pred.device)
-        check(self._ctx, lib().vti_nms(self._ctx, _ptr(pred), B, float(conf), float(iou), int(max_det), int(bool(agnostic)),
-                                       _ptr(dets), _ptr(counts), _stream()))
+        if best is None:
+            check(self._ctx, lib().vti_nms(self._ctx, _ptr(pred), B, float(conf), float(iou), int(max_det), int(bool(agnostic)),
+                                           _ptr(dets), _ptr(counts), _stream()))
+        else:
+            self._check_best(best, B)
+            check(self._ctx, lib().vti_nms_scored(self._ctx, _ptr(pred), _ptr(best), B, float(conf), float(iou), int(max_det),
+                                                  int(bool(agnostic)), _ptr(dets), _ptr(counts), _stream()))
         return dets, counts
 
     def masks(self, dets, counts, proto, mode="logit", packing="u8", capacity=None, masks=None, offsets=None):
@@ -186,6 +204,7 @@ class Engine:
             offsets=torch.empty((B + 1,), dtype=torch.int32, device=dev),
             xyxy=torch.empty((B, max_det, 4), dtype=torch.float32, device=dev),
             input=torch.empty((B, self.H, self.W, 3), dtype=torch.uint8, device=dev),
+            best=self.alloc_best(B, dev),
         )
 
     def predict_into(self, frames, out, conf=0.25, iou=0.7, max_det=300, agnostic=False, swap_rb=True,
