@@ -45,6 +45,7 @@ MFMA_PEAK_TFLOPS = 2517.0      # dense fp16: 256 CU x 4 SIMD x 1024 FLOP/clk x 2
 F32_MFMA_PEAK_TFLOPS = 157.3   # f32-input MFMA (v_mfma_f32_16x16x4_f32): 64 FLOP/clk/SIMD = 1/16 of the fp16 rate (same guide)
 HBM_PEAK_GBS = 8000.0
 CONF, IOU, MAX_DET = 0.25, 0.7, 300      # Ultralytics predict() defaults
+UNSCORED = os.environ.get("VTI_BENCH_UNSCORED") == "1"     # A/B aid: vti_forward + vti_nms (class scores re-scanned) instead of the scored pair
 SLOTS_PER_FRAME = 64                     # mask output capacity = B * SLOTS_PER_FRAME instances (shared by the batch)
 
 
@@ -143,9 +144,9 @@ def fp32_engine_line(vti_amd, blob, frames, B, H, W, nc, cap, dev, n_par, steps=
 
     def step(i=None):
         if i is not None: ev[2 * i].record(st)
-        eng.forward(frames, True, pred=o["pred"], proto=o["proto"], best=o["best"])
+        eng.forward(frames, True, pred=o["pred"], proto=o["proto"], best=None if UNSCORED else o["best"])
         if i is not None: ev[2 * i + 1].record(st)
-        eng.nms(o["pred"], CONF, IOU, MAX_DET, False, dets=o["dets"], counts=o["counts"], best=o["best"])
+        eng.nms(o["pred"], CONF, IOU, MAX_DET, False, dets=o["dets"], counts=o["counts"], best=None if UNSCORED else o["best"])
         eng.masks(o["dets"], o["counts"], o["proto"], "logit", "bits", capacity=cap, masks=o["masks"], offsets=o["offsets"])
         eng.scale_boxes(o["dets"], o["counts"], H, W, xyxy=o["xyxy"])
     for _ in range(warmup):
@@ -263,7 +264,7 @@ def main():
             main_stream.wait_event(post_done[cur])   # post of step k-2 no longer reads outs[cur]
         if timed_idx is not None:
             ev_f0[timed_idx].record(main_stream)
-        eng.forward(x, True, pred=o["pred"], proto=o["proto"], best=o["best"])
+        eng.forward(x, True, pred=o["pred"], proto=o["proto"], best=None if UNSCORED else o["best"])
         if timed_idx is not None:
             ev_f1[timed_idx].record(main_stream)
         fwd_done[cur].record(main_stream)
@@ -271,7 +272,7 @@ def main():
             post_stream.wait_event(fwd_done[cur])
             if timed_idx is not None:
                 ev_p0[timed_idx].record(post_stream)
-            eng.nms(o["pred"], CONF, IOU, MAX_DET, False, dets=o["dets"], counts=o["counts"], best=o["best"])
+            eng.nms(o["pred"], CONF, IOU, MAX_DET, False, dets=o["dets"], counts=o["counts"], best=None if UNSCORED else o["best"])
             eng.masks(o["dets"], o["counts"], o["proto"], "logit", "bits", capacity=cap, masks=o["masks"], offsets=o["offsets"])
             eng.scale_boxes(o["dets"], o["counts"], H, W, xyxy=o["xyxy"])
             if exchange:                    # consumer reductions straight from the bit-packed masks: the gather's payload
@@ -330,11 +331,11 @@ def main():
     # the forward alone (nothing else on the chip), HIP events on the launch stream, right after the timed region
     iso0, iso1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     n_iso = max(5, min(20, args.steps))
-    eng.forward(shards[0], True, pred=outs[0]["pred"], proto=outs[0]["proto"], best=outs[0]["best"])
+    eng.forward(shards[0], True, pred=outs[0]["pred"], proto=outs[0]["proto"], best=None if UNSCORED else outs[0]["best"])
     torch.cuda.synchronize()
     iso0.record(main_stream)
     for _ in range(n_iso):
-        eng.forward(shards[0], True, pred=outs[0]["pred"], proto=outs[0]["proto"], best=outs[0]["best"])
+        eng.forward(shards[0], True, pred=outs[0]["pred"], proto=outs[0]["proto"], best=None if UNSCORED else outs[0]["best"])
     iso1.record(main_stream)
     torch.cuda.synchronize()
     iso_ms = iso0.elapsed_time(iso1) / n_iso

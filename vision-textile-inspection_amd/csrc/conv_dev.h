@@ -440,9 +440,15 @@ __device__ __forceinline__ void conv_stage2(const ConvParams& p, f32x4 (&acc)[MR
                     else v[j] = 1.0f / (1.0f + expf(-v[j]));
                 }
                 if (want_best) {
+                    if ((p.Cout2 & 3) == 0) {       // (wave-uniform) whole quads only: no per-class bound test
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (cout0 + j < p.Cout2 && v[j] > bv) { bv = v[j]; bc = cout0 + j; }
+                        for (int j = 0; j < 4; ++j)
+                            if (v[j] > bv) { bv = v[j]; bc = cout0 + j; }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (cout0 + j < p.Cout2 && v[j] > bv) { bv = v[j]; bc = cout0 + j; }
+                    }
                 }
             }
             if (!pvalid[m]) continue;

@@ -575,10 +575,40 @@ __device__ __forceinline__ bool mask_tile_rect(const float* __restrict__ d, int 
 // 4096-slot buffer holding three instances costs three slots of writes, not a memset of the whole buffer.  Whole slots, full
 // lines: zeroing only the bytes outside each slot's tile rectangle was tried and is slower (partial-line writes: 109 MB took
 // 50 us where this takes ~23 us for 181 MB).  One workgroup per slot.
-__global__ __launch_bounds__(256) void mask_clear_kernel(const int* __restrict__ offsets, int B, int slot_bytes, int capacity,
-                                                         uint8_t* __restrict__ masks) {
+// FUSED_OFFSETS (B <= 1024): the launch also does mask_offsets_kernel's job -- every workgroup sums the clamped counts for itself
+// (that is the number of live slots), workgroup 0 writes the prefix sums; one launch less in front of the tile kernel.
+template <bool FUSED_OFFSETS>
+__global__ __launch_bounds__(256) void mask_clear_kernel(const int* __restrict__ counts, int* __restrict__ offsets, int* __restrict__ nitems,
+                                                         int B, int max_det, int slot_bytes, int capacity, uint8_t* __restrict__ masks) {
     const int slot = blockIdx.x;
-    if (slot >= min(offsets[B], capacity)) return;
+    int total;
+    if constexpr (FUSED_OFFSETS) {
+        __shared__ int s_c[1025];
+        __shared__ int s_tot;
+        if (threadIdx.x == 0) s_tot = 0;
+        __syncthreads();
+        int part = 0;
+        for (int b = threadIdx.x; b < B; b += 256) {
+            const int c = counts[b], cc = c < 0 ? 0 : (c > max_det ? max_det : c);
+            part += cc;
+            if (slot == 0) s_c[b + 1] = cc;
+        }
+        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+        if ((threadIdx.x & 63) == 0) atomicAdd(&s_tot, part);
+        __syncthreads();
+        total = s_tot;
+        if (slot == 0) {
+            if (threadIdx.x == 0) {
+                s_c[0] = 0; *nitems = 0;
+                for (int b = 0; b < B; ++b) s_c[b + 1] += s_c[b];
+            }
+            __syncthreads();
+            for (int b = threadIdx.x; b <= B; b += 256) offsets[b] = s_c[b];
+        }
+    } else {
+        total = offsets[B];
+    }
+    if (slot >= min(total, capacity)) return;
     uint4* b4 = (uint4*)(masks + (size_t)slot * slot_bytes);       // slot_bytes % 16 == 0 (checked by the launcher)
     const int nvec = slot_bytes >> 4;
     for (int v = threadIdx.x; v < nvec; v += 256) b4[v] = make_uint4(0u, 0u, 0u, 0u);
@@ -1077,12 +1107,16 @@ hipError_t launch_masks(int dtype, const float* dets, const int* counts, const v
     int* nitems = (int*)ws;
     int2* items = (int2*)((char*)ws + 256);
     if (max_det > 65535 || B > 32767 || H > 64 * MT || W > 64 * MT || capacity > (1 << 19)) return hipErrorInvalidValue;    // item record fields
-    hipLaunchKernelGGL(mask_offsets_kernel, dim3(1), dim3(256), (size_t)(B + 1) * sizeof(int), st, counts, B, max_det, offsets, nitems);
-    if (capacity <= 0) return hipGetLastError();
     const size_t slot_bytes = (size_t)H * (packing == VTI_PACK_U8 ? W : W / 8);      // H, W multiples of 32: a multiple of 128
-    if ((slot_bytes & 15) || ((uintptr_t)masks & 15)) return hipErrorInvalidValue;
-    // (running the clear on a side stream next to the plan was tried: the two event hops cost more than the 13 us they hide)
-    hipLaunchKernelGGL(mask_clear_kernel, dim3(capacity), dim3(256), 0, st, offsets, B, (int)slot_bytes, capacity, masks);
+    if (capacity > 0 && ((slot_bytes & 15) || ((uintptr_t)masks & 15))) return hipErrorInvalidValue;
+    if (capacity > 0 && B <= 1024) {
+        hipLaunchKernelGGL(mask_clear_kernel<true>, dim3(capacity), dim3(256), 0, st, counts, offsets, nitems, B, max_det, (int)slot_bytes, capacity, masks);
+    } else {
+        hipLaunchKernelGGL(mask_offsets_kernel, dim3(1), dim3(256), (size_t)(B + 1) * sizeof(int), st, counts, B, max_det, offsets, nitems);
+        if (capacity <= 0) return hipGetLastError();
+        // (running the clear on a side stream next to the plan was tried: the two event hops cost more than the 13 us they hide)
+        hipLaunchKernelGGL(mask_clear_kernel<false>, dim3(capacity), dim3(256), 0, st, counts, offsets, nitems, B, max_det, (int)slot_bytes, capacity, masks);
+    }
     // persistent blocks walk the work list: exactly as many as are resident at once (a second round of late blocks would run
     // on a mostly empty chip), a multiple of 8 for the per-XCD partition
     static int per_cu_dev[kMaxDevices][4] = {};
