@@ -46,14 +46,19 @@ size_t conv_lds_bytes(int ks, int stride, int mode, int TH, int TW, int WN, int 
 // Register-staged operand prefetch: a thread owns up to AR input-patch pieces and BR weight pieces
 // (16 B each) of a chunk.  issue() only starts the loads; commit() writes them to LDS.  The next chunk is
 // issued before the MFMA loop of the current one, so HBM/L2 latency hides under MFMA.
-template <typename T, int KS, int S, int NREP, int WN, int NREP2 = 0>
-__global__ __launch_bounds__(256, 2) void conv_kernel(const ConvParams p) {   // 2 waves/SIMD: VGPR + AGPR <= 256
+// NT = 512 (fused head towers on the 80-wide maps): ONE 8-wave workgroup per CU on a 16 x 40 tile instead of two 4-wave workgroups on
+// 16 x 20 tiles -- the same 2 waves per SIMD, but a staged weight chunk (45 KB for the 80-channel class tower) now serves 640 pixels
+// instead of 320 (the towers' weights were re-staged from L2 once per 320 pixels: 690 MB per launch), and with half the weight pieces
+// per thread even the NREP = 5 kernels can prefetch them into registers under the MFMA loop instead of fetching them in commit().
+template <typename T, int KS, int S, int NREP, int WN, int NREP2 = 0, int NT = 256>
+__global__ __launch_bounds__(NT, NT == 512 ? 1 : 2) void conv_kernel(const ConvParams p) {   // 2 waves/SIMD: VGPR + AGPR <= 256
     using vec = typename Tr<T>::vec;
     constexpr int VEC = Tr<T>::VEC, KC = Tr<T>::KC;
     constexpr int TAPS = KS * KS, PAD = KS / 2;
     constexpr int NTB = WN * NREP;
-    constexpr int AR = (S == 2 ? 12 : 8);
-    constexpr int BR = (NTB * TAPS * 64 + 255) / 256;
+    constexpr int PP = NT / 4;                               // pixels of the input patch per staging pass (4 lanes per pixel)
+    constexpr int AR = NT == 512 ? 6 : (S == 2 ? 12 : 8);
+    constexpr int BR = (NTB * TAPS * 64 + NT - 1) / NT;
     constexpr unsigned OOB = 0xFFFFFFFFu;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -101,16 +106,16 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvParams p) {   //
 
     // item -> (pixel, 16-B channel piece q): 8 consecutive lanes take 8 consecutive pixels of ONE plane (a
     // conflict-free 128-B ds_write run); a wave instruction still covers 16 pixels x 64 B of global memory.
-    // item i = tid + 256*u  ->  pixel = (tid>>5)*8 + (tid&7) + 64*u, q = (tid>>3)&3 (same q for every u).
+    // item i = tid + NT*u  ->  pixel = (tid>>5)*8 + (tid&7) + (NT/4)*u, q = (tid>>3)&3 (same q for every u).
     const int iy0 = oy0 * S - PAD, ix0 = ox0 * S - PAD;
     const int q = (tid >> 3) & 3;
     const int pix0 = (tid >> 5) * 8 + (tid & 7);
-    const int ldsA0 = q * plane_bytes + pix0 * 16;          // + u * 1024 per piece
+    const int ldsA0 = q * plane_bytes + pix0 * 16;          // + u * PP * 16 per piece
     const int cvalid = (p.Cin - q * VEC + KC - 1) / KC;     // chunks in which this lane's channel piece exists
     unsigned aoff[AR];
 #pragma unroll
     for (int u = 0; u < AR; ++u) {
-        const int pix = pix0 + 64 * u;
+        const int pix = pix0 + PP * u;
         const int py = (int)__umulhi((unsigned)pix, p.pw_magic), px = pix - py * PW;
         const int y = iy0 + py, x = ix0 + px;
         const bool ok = pix < npix && (unsigned)y < (unsigned)p.Hin && (unsigned)x < (unsigned)p.Win;
@@ -118,7 +123,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvParams p) {   //
     }
     // NREP == 5 kernels are at the register limit: they fetch the weight pieces synchronously inside commit()
     // (short-lived registers, L2-resident data) instead of carrying them across the MFMA loop.
-    constexpr bool BPRE = NREP < 5;
+    constexpr bool BPRE = NREP < 5 || NT == 512;
     // Register sets of staged operands.  1x1 convs on the small maps are a chain of short K chunks (20 MFMAs each) whose cost is the
     // memory round trip per chunk: they keep TWO chunks in flight (their staging registers are few: no taps, no halo).
     constexpr int PD = (KS == 1 && BPRE) ? 2 : 1;
@@ -127,13 +132,13 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvParams p) {   //
         const unsigned sB = (unsigned)(((size_t)c * p.ntiles_n + nt0) * (TAPS * 1024));
 #pragma unroll
         for (int u = 0; u < BR; ++u)
-            if (tid + u * 256 < NTB * TAPS * 64) rbs[u] = buf_load16<vec>(rsB, (unsigned)(tid + u * 256) * 16u, sB);
+            if (tid + u * NT < NTB * TAPS * 64) rbs[u] = buf_load16<vec>(rsB, (unsigned)(tid + u * NT) * 16u, sB);
     };
     auto issue = [&](int c, vec (&ras)[AR], vec (&rbs)[BR]) {
         const bool qok = c < cvalid;
 #pragma unroll
         for (int u = 0; u < AR; ++u)
-            if (pix0 + 64 * u < ((npix + 7) & ~7))
+            if (pix0 + PP * u < ((npix + 7) & ~7))
                 ras[u] = buf_load16<vec>(rsA, qok ? aoff[u] : OOB, (unsigned)(c * KC * (int)sizeof(T)));
         if constexpr (BPRE) loadB(c, rbs);
     };
@@ -141,10 +146,10 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvParams p) {   //
         if constexpr (!BPRE) loadB(c, rbs);
 #pragma unroll
         for (int u = 0; u < AR; ++u)
-            if (pix0 + 64 * u < npix) *(vec*)(smA + ldsA0 + u * 1024) = ras[u];
+            if (pix0 + PP * u < npix) *(vec*)(smA + ldsA0 + u * (PP * 16)) = ras[u];
 #pragma unroll
         for (int u = 0; u < BR; ++u)
-            if (tid + u * 256 < NTB * TAPS * 64) *(vec*)(smB + (tid + u * 256) * 16) = rbs[u];
+            if (tid + u * NT < NTB * TAPS * 64) *(vec*)(smB + (tid + u * NT) * 16) = rbs[u];
     };
     // one K chunk: commit its operands (register set SET), refill that set with chunk c + PD, MFMA over the taps
     auto chunk = [&](int c, auto set_c) {
@@ -781,17 +786,18 @@ hipError_t launch_stem_l1(int dtype, const ConvParams& p, hipStream_t st) {
 size_t stem_lds_bytes(int TH, int TW) { return 1024 + (size_t)(2 * TH + 1) * ((((2 * TW + 1) * 3 + 6) >> 2) * 4); }
 
 // Host-side check that a geometry fits the kernel's fixed register staging arrays.
-bool conv_cfg_fits(int ks, int stride, int mode, int TH, int TW, int WN, int NREP) {
+bool conv_cfg_fits(int ks, int stride, int mode, int TH, int TW, int WN, int NREP, int threads) {
     if (mode == 1) return WN == 1 && (2 * TH + 1) * (((2 * TW + 1) * 3 + 6) >> 2) < 65536;
-    const int AR = stride == 2 ? 12 : 8;
+    if (threads != 256 && !(threads == 512 && ks == 3 && stride == 1 && WN == 1)) return false;
+    const int AR = threads == 512 ? 6 : (stride == 2 ? 12 : 8);
     const int npix = patch_dim(TH, ks, stride, mode) * patch_dim(TW, ks, stride, mode);
-    if (((npix + 7) / 8) * 32 > 256 * AR) return false;     // input pieces per thread
+    if (((npix + 7) / 8) * 32 > threads * AR) return false;     // input pieces per thread
     return ks == 1 || WN * NREP <= 5;                        // 3x3 instantiations cover WN*NREP <= 5
 }
 
-template <typename T, int KS, int S, int NREP, int WN, int NREP2 = 0>
+template <typename T, int KS, int S, int NREP, int WN, int NREP2 = 0, int NT = 256>
 static hipError_t launch_one(const ConvParams& p, dim3 grid, size_t lds, hipStream_t st) {
-    auto k = conv_kernel<T, KS, S, NREP, WN, NREP2>;
+    auto k = conv_kernel<T, KS, S, NREP, WN, NREP2, NT>;
     static size_t lds_ok_dev[kMaxDevices] = {};
     size_t& lds_ok = lds_ok_dev[current_device_slot()];
     if (lds > 64 * 1024 && lds > lds_ok) {
@@ -799,7 +805,7 @@ static hipError_t launch_one(const ConvParams& p, dim3 grid, size_t lds, hipStre
         if (e != hipSuccess) return e;
         lds_ok = 160 * 1024;
     }
-    hipLaunchKernelGGL(k, grid, dim3(256), lds, st, p);
+    hipLaunchKernelGGL(k, grid, dim3(NT), lds, st, p);
     return hipGetLastError();
 }
 
@@ -821,7 +827,7 @@ bool conv_fusable(int nrep, int nrep2) {
 
 template <typename T>
 static hipError_t launch_fused(int nrep, int nrep2, const ConvParams& p, dim3 grid, size_t lds, hipStream_t st) {
-#define VTI_F(N, N2) if (nrep == N && nrep2 == N2) return launch_one<T, 3, 1, N, 1, N2>(p, grid, lds, st);
+#define VTI_F(N, N2) if (nrep == N && nrep2 == N2) return p.nt == 512 ? launch_one<T, 3, 1, N, 1, N2, 512>(p, grid, lds, st) : launch_one<T, 3, 1, N, 1, N2>(p, grid, lds, st);
     VTI_F(2, 2) VTI_F(3, 2) VTI_F(4, 1) VTI_F(4, 2) VTI_F(4, 4) VTI_F(4, 5) VTI_F(5, 5)
 #undef VTI_F
     return hipErrorInvalidValue;
@@ -858,7 +864,9 @@ hipError_t launch_conv(int dtype, int ks, int stride, int nrep, int mode, const 
     dim3 grid((unsigned)(p.B * p.tiles_y * p.tiles_x), (unsigned)((p.ntiles_n + NTB - 1) / NTB));
     if (grid.x == 0) return hipSuccess;
     // host-side shape guard: the pixel tile must fit the 4/WN waves x 5 x 16 pixels
-    if (p.TH * p.TW > (4 / p.WN) * MREP * 16 || (p.WN != 1 && p.WN != 2 && p.WN != 4)) return hipErrorInvalidValue;
+    const int nwaves = p.nt == 512 ? 8 : 4;
+    if ((p.nt != 256 && p.nt != 512) || (p.nt == 512 && p.ntiles2 == 0)) return hipErrorInvalidValue;     // 512 threads: fused towers only
+    if (p.TH * p.TW > (nwaves / p.WN) * MREP * 16 || (p.WN != 1 && p.WN != 2 && p.WN != 4)) return hipErrorInvalidValue;
     if (dtype == VTI_F16) return launch_t<half_t>(ks, stride, nrep, mode, p, grid, lds_bytes, st);
     return launch_t<float>(ks, stride, nrep, mode, p, grid, lds_bytes, st);
 }

@@ -705,6 +705,19 @@ std::string Plan::build(const vti_desc& d) {
         else if (op.fused >= 0) {   // whole Cout in one wave; the per-tile kernel (2 workgroups per CU) hides the long fused epilogue better
             const char* pf = getenv("VTI_PK_FUSED");
             choose_conv_cfg(d.dtype, r, false, d.max_batch, op.cfg, 0, 0, 1, r.c2 / 16, pk_ok && pf && pf[0] == '1');
+            // 8-wave workgroups on 16 x 40 tiles where such tiles cover the map as well as the chosen ones (the 80-wide level: most
+            // of the towers' time): half the weight staging per pixel (conv.hip, NT = 512)
+            const char* n5 = getenv("VTI_NO_T512");
+            if (!(n5 && n5[0] == '1') && !op.cfg.pk && op.cfg.TH && r.k == 3 && r.s == 1 && r.kind == 0) {
+                const int TH = 16, TW = 40;
+                const double eff_now = (double)r.h_out * r.w_out / ((double)((r.h_out + op.cfg.TH - 1) / op.cfg.TH) * ((r.w_out + op.cfg.TW - 1) / op.cfg.TW) * op.cfg.TH * op.cfg.TW);
+                const double eff_512 = (double)r.h_out * r.w_out / ((double)((r.h_out + TH - 1) / TH) * ((r.w_out + TW - 1) / TW) * TH * TW);
+                const size_t lds = conv_lds_bytes(3, 1, 0, TH, TW, 1, op.cfg.NREP);
+                const size_t wgs = (size_t)((r.h_out + TH - 1) / TH) * ((r.w_out + TW - 1) / TW) * d.max_batch;
+                if (eff_512 >= eff_now - 1e-9 && lds <= 160 * 1024 && wgs >= 512 && conv_cfg_fits(3, 1, 0, TH, TW, 1, op.cfg.NREP, 512)) {
+                    op.cfg.TH = TH; op.cfg.TW = TW; op.cfg.threads = 512; op.cfg.lds = lds;
+                }
+            }
         }
         else choose_conv_cfg(d.dtype, r, op.kind == OP_CONV0, d.max_batch, op.cfg, 0, 0, 0, 0, pk_ok);
         if (op.cfg.TH == 0) return "no launch configuration for conv " + r.name;

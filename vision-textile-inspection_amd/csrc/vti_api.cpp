@@ -250,6 +250,7 @@ static void fill_conv_params(int conv_elem_size, ConvParams& p, const ConvRow& r
     p.TH = g.TH; p.TW = g.TW;
     p.tiles_y = (p.Hout + g.TH - 1) / g.TH; p.tiles_x = (p.Wout + g.TW - 1) / g.TW;
     p.WN = g.WN;
+    p.nt = g.threads;
     p.act = r.kind == 0; p.out_f32 = out_f32 ? 1 : 0;
     p.deconv_c = deconv ? r.c2 : 0;
     p.swap_rb = swap_rb ? 1 : 0;

@@ -61,6 +61,7 @@ struct ConvCfg {         // launch geometry chosen at plan time
     // persistent LDS-DMA kernel (conv_pk.hip): TW = 20, TH = 4 * M-waves; wgpc = co-resident workgroups per CU
     int pk = 0, pk_wgpc = 1;         // pk: 1 = conv3_pk, 2 = conv1_pk (TH = compute waves along M, TW = 80), 3 = bneck_pk (fused 3x3 -> 3x3 pair), 4 = conv3_pk stride 2
     int pk_depth = 2, pk_wstat = 0;  // conv1_pk: stage-ring depth, weights stationary in LDS
+    int threads = 256;               // per-tile kernel: 256, or 512 (fused towers on wide maps: one 8-wave workgroup per CU, 16 x 40 tiles)
 };
 
 struct Op {
@@ -120,6 +121,7 @@ struct ConvParams {
     // fused 1x1 second stage: out2 = act2(W2 . silu(conv + bias) + bias2), never touching HBM in between
     const void* w2; const float* bias2; void* out2;
     int Cout2, ntiles2, out2_ld, out2_coff, act2 /*0 none, 1 SiLU, 2 sigmoid, 3 DFL + dist2bbox*/, out2_f32, scalar_store2, nat2, out2_bstride;
+    int nt;           // threads per workgroup of the per-tile kernel (256 / 512)
     float* best;      // act2 == 2 (class scores into pred): also (max score, its first class) per anchor -> best[(b * out2_bstride + pixel) * 2], or null
     float dfl_stride;
     // persistent kernel (conv_pk.hip): tile count, workgroups along x, XCD-contiguous tile ranges, tensor sizes
@@ -137,7 +139,7 @@ hipError_t launch_conv(int dtype, int ks, int stride, int nrep, int mode, const 
                        size_t lds_bytes, hipStream_t st);
 bool conv_fusable(int nrep, int nrep2);   // is there a (3x3 NREP) + (1x1 NREP2) fused instantiation
 size_t conv_lds_bytes(int ks, int stride, int mode, int TH, int TW, int WN, int NREP);
-bool conv_cfg_fits(int ks, int stride, int mode, int TH, int TW, int WN, int NREP);
+bool conv_cfg_fits(int ks, int stride, int mode, int TH, int TW, int WN, int NREP, int threads = 256);
 // stem (3->16, k3 s2) + layer 1 (16->32, k3 s2) in one kernel: 16 x 20 layer-1 output tiles
 hipError_t launch_stem_l1(int dtype, const ConvParams& p, hipStream_t st);
 size_t stem_l1_lds_bytes(int dtype);
