@@ -107,7 +107,7 @@ hipError_t launch_letterbox(const uint8_t* frames, int B, int H0, int W0, uint8_
 // =====================================================================================
 // U6 non_max_suppression -- one 1024-thread workgroup per frame
 // =====================================================================================
-constexpr int NMS_THREADS = 512;
+constexpr int NMS_THREADS = 1024;
 constexpr int NMS_LDS_BOX = 2048;         // sorted boxes/areas/keep list live in LDS up to this many candidates
 constexpr int NMS_LDS_KEYS = 2048;        // == NMS_LDS_BOX: beyond this many candidates everything lives in global scratch
 constexpr float NMS_MAX_WH = 7680.0f;     // Ultralytics class offset
@@ -292,24 +292,24 @@ __device__ __forceinline__ void nms_body(const float* __restrict__ P, int A, int
         const int cnt = min(64, n - base);
         if (tid < 64) s_rows[tid] = 0;
         __syncthreads();
-        // A: thread -> (row i, 8 columns)
-        for (int e = tid; e < 64 * 8; e += NMS_THREADS) {
-            const int i = e >> 3, jg = (e & 7) * 8;
-            if (i >= cnt || jg + 7 <= i) continue;
+        // A: thread -> (row i, 4 columns)
+        for (int e = tid; e < 64 * 16; e += NMS_THREADS) {
+            const int i = e >> 4, jg = (e & 15) * 4;
+            if (i >= cnt || jg + 3 <= i) continue;
             const f32x4 bi = boxes[base + i];
             const float ai = area[base + i];
             unsigned long long m = 0;
-            f32x4 bj8[8];
-            float aj8[8];
+            f32x4 bj4[4];
+            float aj4[4];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {          // the 8 operands first (clamped index), then the tests: no wait per pair
+            for (int k = 0; k < 4; ++k) {          // the 4 operands first (clamped index), then the tests: no wait per pair
                 const int jc = jg + k < cnt ? jg + k : cnt - 1;
-                bj8[k] = boxes[base + jc]; aj8[k] = area[base + jc];
+                bj4[k] = boxes[base + jc]; aj4[k] = area[base + jc];
             }
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
+            for (int k = 0; k < 4; ++k) {
                 const int j = jg + k;
-                if (j > i && j < cnt && iou_gt(bi, ai, bj8[k], aj8[k])) m |= 1ull << j;
+                if (j > i && j < cnt && iou_gt(bi, ai, bj4[k], aj4[k])) m |= 1ull << j;
             }
             if (m) atomicOr(&s_rows[i], m);
         }
@@ -337,15 +337,20 @@ __device__ __forceinline__ void nms_body(const float* __restrict__ P, int A, int
         const int kept0 = kept;           // keep[kept0 .. kept) are this block's kept candidates, in order
         kept = s_kept;
         // C: later candidates vs this block's kept boxes, four at a time (operands of a group loaded together; a candidate
-        // is suppressed iff ANY kept box of the block overlaps it, so the order of the tests does not matter)
+        // is suppressed iff ANY kept box of the block overlaps it, so the order of the tests does not matter).  With fewer
+        // candidates left than threads, `parts` threads share a candidate and split the kept boxes between them.
         if (kept < max_det) {
             const int nk = kept - kept0;
-            for (int j = base + 64 + tid; j < n; j += NMS_THREADS) {
+            const int rest = n - (base + 64);
+            int parts = 1;
+            while (parts < 8 && rest * parts * 2 <= NMS_THREADS) parts <<= 1;
+            const int part = tid & (parts - 1), lane_j = tid / parts, jstep = NMS_THREADS / parts;
+            for (int j = base + 64 + lane_j; j < n; j += jstep) {
                 if (suppressed[j]) continue;
                 const f32x4 bj = boxes[j];
                 const float aj = area[j];
                 bool sup = false;
-                for (int t = 0; t < nk && !sup; t += 4) {
+                for (int t = 4 * part; t < nk && !sup; t += 4 * parts) {
                     int ii[4];
                     f32x4 bk[4];
                     float ak[4];
