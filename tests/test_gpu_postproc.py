@@ -269,3 +269,49 @@ def test_consumer_reductions_exact():
     _, env = eng.union_envelope(bm, [0])
     st = eng.mask_stats(bm).cpu().numpy()[0]
     assert env.cpu().tolist() == c["envelope"] and st.tolist() == [c["m00"], c["m10"], c["m01"], c["min_col"], c["max_col"]]
+
+
+@pytest.mark.parametrize("dtype", ["fp16", "fp32"])
+@pytest.mark.parametrize("H,W", [(224, 288), (640, 640)])
+def test_masks_crowded_tiles_rounds_and_ragged_width(dtype, H, W):
+    """The grouped tile kernel's corner cases in one frame set: 90 large overlapping boxes (more than 64 instances per frame: two
+    list rounds; more than 16 per tile: several MFMA groups), a frame with 3 and a frame with none; W = 288 has a half tile column
+    and 36-byte bit rows (4-byte aligned only); one instance carries coefficients beyond fp16 range (the power-of-two rescue of the
+    split) and one has a zero-area box.  Both packings, both mask modes, against process_mask."""
+    need_gpu()
+    import vti_amd
+    eng = _engine(nc=2, H=H, W=W, B=3, dtype=dtype)
+    rng = np.random.default_rng(23)
+    B, max_det = 3, 128
+    dets = np.zeros((B, max_det, 38), np.float32)
+    n = [90, 3, 0]
+    for b in range(B):
+        for i in range(n[b]):
+            w, h = rng.uniform(0.3, 0.8) * W, rng.uniform(0.3, 0.8) * H
+            x1, y1 = rng.uniform(0, W - w), rng.uniform(0, H - h)
+            dets[b, i, :4] = [x1, y1, x1 + w, y1 + h]
+            dets[b, i, 4], dets[b, i, 5] = 0.9 - 0.001 * i, i % 2
+            dets[b, i, 6:] = rng.standard_normal(32)
+    dets[0, 5, 6:] *= 1.0e5                                  # |c| >= 3e4: outside the half range of the split
+    dets[0, 7, :4] = [40.0, 40.0, 40.0, 40.0]                # empty crop box: an all-zero mask
+    tdt = torch.float16 if dtype == "fp16" else torch.float32
+    proto = torch.from_numpy(rng.standard_normal((B, H // 4, W // 4, 32)).astype(np.float32)).to(tdt).cuda()
+    dd, cc = torch.from_numpy(dets).cuda(), torch.tensor(n, dtype=torch.int32).cuda()
+    for mode in ("logit", "sigmoid"):
+        masks, off = eng.masks(dd, cc, proto, mode, "u8")
+        bits, off2 = eng.masks(dd, cc, proto, mode, "bits")
+        torch.cuda.synchronize()
+        assert off.cpu().tolist() == [0, 90, 93, 93] and torch.equal(off, off2)
+        assert torch.equal(vti_amd.unpack_bits(bits, W), masks)
+        worst = 1.0
+        for b in range(2):
+            d = dets[b, :n[b]]
+            ref = process_mask(proto[b].float().cpu().permute(2, 0, 1), d[:, 6:], d[:, :4], (H, W), mode).numpy()
+            got = masks[int(off[b]):int(off[b + 1])].cpu().numpy()
+            for i in range(n[b]):
+                if ref[i].sum() == 0:
+                    assert got[i].sum() == 0, (b, i)
+                else:
+                    worst = min(worst, mask_iou(got[i], ref[i]))
+        assert worst >= 0.999, (mode, worst)
+        assert int(masks[7].sum()) == 0
