@@ -819,16 +819,37 @@ __device__ __forceinline__ void mask_tile_rows64(const float* lrow, float wy, bo
         vv[j] = __builtin_fmaf(b - a, wy, a);
     }
     unsigned w[2] = {0u, 0u};
+    if (thr == 0.0f) {
+        // logits against 0 (wave-uniform): the bit is the SIGN of -v, shifted in by v_alignbit -- two instructions per 64 pixels.
+        // -v = fma(vv[j] - vv[j+1], wx, -vv[j]) is the exact negation of the blend below (round-to-nearest is symmetric), and it is
+        // never -0: a zero sum of non-zero terms is +0, cropped taps are +0 and x - x is +0, so v = 0 gives bit 0 as v > 0 does.
+        // (A NaN logit -- non-finite coefficients -- has no defined sign: the low-res tile is written without NaNs.)
 #pragma unroll
-    for (int hf = 0; hf < 2; ++hf) {
+        for (int j = 0; j < 18; ++j) vv[j] = -vv[j];
 #pragma unroll
-        for (int k = 31; k >= 0; --k) {
-            const int px = 32 * hf + k;
-            const int jj = ((px - 2) >> 2) + 1;                           // 0 .. 16
-            const float wx = 0.125f + 0.25f * (float)((px + 2) & 3);
-            float v = __builtin_fmaf(vv[jj + 1] - vv[jj], wx, vv[jj]);
-            if (px < 2) v = first ? vv[1] : v;
-            asm("v_cmp_gt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(w[hf]) : "v"(v), "v"(thr) : "vcc");
+        for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+            for (int k = 31; k >= 0; --k) {
+                const int px = 32 * hf + k;
+                const int jj = ((px - 2) >> 2) + 1;                       // 0 .. 16
+                const float wx = 0.125f + 0.25f * (float)((px + 2) & 3);
+                float u = __builtin_fmaf(vv[jj + 1] - vv[jj], wx, vv[jj]);
+                if (px < 2) u = first ? vv[1] + 0.0f : u;                 // (-0) + (+0) = +0: a cropped tap must not read as negative
+                w[hf] = __builtin_amdgcn_alignbit(w[hf], __builtin_bit_cast(unsigned, u), 31);     // (w << 1) | sign(u)
+            }
+        }
+    } else {
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+            for (int k = 31; k >= 0; --k) {
+                const int px = 32 * hf + k;
+                const int jj = ((px - 2) >> 2) + 1;                       // 0 .. 16
+                const float wx = 0.125f + 0.25f * (float)((px + 2) & 3);
+                float v = __builtin_fmaf(vv[jj + 1] - vv[jj], wx, vv[jj]);
+                if (px < 2) v = first ? vv[1] : v;
+                asm("v_cmp_gt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(w[hf]) : "v"(v), "v"(thr) : "vcc");
+            }
         }
     }
     lo = w[0]; hi = w[1];
@@ -1054,7 +1075,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 4 : 3) void masks_group_kerne
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const bool inb = pfc >= rb[r].x && pfc < rb[r].z && pfr >= rb[r].y && pfr < rb[r].w;
-                        (&low[4 * lg + r][0][0])[pla] = inb ? v[r] : 0.f;
+                        (&low[4 * lg + r][0][0])[pla] = (inb && v[r] == v[r]) ? v[r] : 0.f;       // cropped, or NaN (non-finite coefficients): +0
                     }
                 }
                 MASK_T(2);                                                 // coefficients loaded, MFMAs, low-res tiles written
@@ -1134,7 +1155,8 @@ hipError_t launch_masks(int dtype, const float* dets, const int* counts, const v
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 256, 0) != hipSuccess || nb < 1) nb = 4;
         per_cu[kidx] = nb > 8 ? 8 : nb;
     }
-    const int grid = 256 * per_cu[kidx];
+    int grid = 256 * per_cu[kidx];
+    if (const char* e = getenv("VTI_MASK_WGS_PER_CU")) grid = 256 * std::max(1, std::min(per_cu[kidx], atoi(e)));   // experiments: fewer resident workgroups
     if (nm == 32) {
         // the (frame, tile) list is static: no plan, no work-list memory
         if (dtype == VTI_F16)
