@@ -235,7 +235,10 @@ static bool choose_pk1_cfg(int esize, const ConvRow& r, int max_batch, ConvCfg& 
                 if (fth && nwm != fth) continue;
                 const int ncomp = nwm * WN;
                 if (ncomp > 4) continue;
-                const int wstat = (size_t)c.nchunks * NTB * 1024 <= 64 * 1024 ? 1 : 0;
+                // stationary weights up to 96 KB: streaming them with the pixels takes LDS-DMA ingest from the pixels (model.12.cv1, 384 -> 128 at
+                // 40x40: 8 of every 18 KB per step; 36.5 -> 32.6 us with 96 KB stationary and a 6-deep ring).  VTI_PK1_WSTAT_KB: tools/pk1_sweep.py
+                static const size_t wstat_max = getenv("VTI_PK1_WSTAT_KB") ? (size_t)atoi(getenv("VTI_PK1_WSTAT_KB")) * 1024 : 96 * 1024;
+                const int wstat = (size_t)c.nchunks * NTB * 1024 <= wstat_max ? 1 : 0;
                 int depth = 0;
                 for (int dd = 8; dd >= 2; --dd) if (conv1_pk_fits(nwm, WN, NREP, c.nchunks, dd, wstat)) { depth = dd; break; }
                 if (!depth) continue;
@@ -248,7 +251,8 @@ static bool choose_pk1_cfg(int esize, const ConvRow& r, int max_batch, ConvCfg& 
                 const double bytes = (double)total_px * ((double)gy * r.c1 + (double)c.gemm_n) * esize +
                                      (wstat ? 0.0 : (double)NT * gy * c.nchunks * NTB * 1024 * 0.25);   // streamed weights (L2)
                 const double inflight = (double)(depth - 1) * nwm * 80 * 64;                       // bytes in flight per CU
-                const double t_mem = bytes / (5.0e12 * std::min(1.0, inflight / 100e3));
+                static const double inflight_full = getenv("VTI_PK1_INFLIGHT_KB") ? atof(getenv("VTI_PK1_INFLIGHT_KB")) * 1e3 : 50e3;       // bytes in flight per CU that saturate the ingest (measured: ~50 KB)
+                const double t_mem = bytes / (5.0e12 * std::min(1.0, inflight / inflight_full));
                 const double cost = std::max(t_comp, t_mem) + 0.15 * std::min(t_comp, t_mem) + 4e-6;
                 if (cost < best) {
                     best = cost; found = true;
