@@ -257,8 +257,13 @@ __global__ __launch_bounds__(512) void conv3_pk(const ConvParams p) {
     int xa[MREP][3], ry[MREP], rx[MREP];
 #pragma unroll
     for (int m = 0; m < MREP; ++m) {
-        const int pp = m * 16 + (lane & 15);
-        const int py = (pp * 205) >> 12, px = pp - py * PK_TW;      // pp / 20 for pp < 80
+        // column tile m < 4 = the first 16 pixels of tile row m, column tile 4 = the last 4 pixels of the four rows: 16 pixels cut from
+        // the LINEAR 80-pixel run wrap into the next patch row (+5 slots), which puts lanes 0-3 and 12-15 of a ds_read_b128 group on the
+        // same bank quarter with the same swizzle bit -- 3 of 5 column tiles were 2-way conflicted (SQ_LDS_BANK_CONFLICT 25-33 % of the
+        // LDS-active cycles); row runs are conflict-free, the 4 x 4 block stays 2-way.  (p.pk_lin: the old map, for A/B runs.)
+        const int pp = m * 16 + (lane & 15), li = lane & 15;
+        const int py = p.pk_lin ? (pp * 205) >> 12 : (m < 4 ? m : li >> 2);      // pp / 20 for pp < 80
+        const int px = p.pk_lin ? pp - py * PK_TW : (m < 4 ? li : 16 + (li & 3));
         ry[m] = wm * PK_ROWS + py; rx[m] = px;
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) {
@@ -986,8 +991,9 @@ __global__ __launch_bounds__(512) void bneck_pk(const ConvParams p) {
     [[maybe_unused]] int xc[MREP];
 #pragma unroll
     for (int m = 0; m < MREP; ++m) {
-        const int pp = m * 16 + (lane & 15);
-        const int py = (pp * 205) >> 12, px = pp - py * PK_TW;
+        const int pp = m * 16 + (lane & 15), li = lane & 15;                      // row runs + one 4 x 4 block: see conv3_pk
+        const int py = p.pk_lin ? (pp * 205) >> 12 : (m < 4 ? m : li >> 2);
+        const int px = p.pk_lin ? pp - py * PK_TW : (m < 4 ? li : 16 + (li & 3));
         ry[m] = wm * PK_ROWS + py; rx[m] = px;
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) {

@@ -235,6 +235,11 @@ static void* buf_ptr(vti_ctx* c, int buf, const void* input, void* proto) {
     return c->ws + c->plan.bufs[buf].off;
 }
 
+static int pk_linear_map() {       // A/B aid: VTI_PK_LINEAR_MAP=1 restores the linear pixel -> column-tile map of the persistent 3x3 kernels
+    static const int v = getenv("VTI_PK_LINEAR_MAP") && getenv("VTI_PK_LINEAR_MAP")[0] == '1';
+    return v;
+}
+
 // One conv launch's parameter block from its table row + geometry + tensor views.
 static void fill_conv_params(int conv_elem_size, ConvParams& p, const ConvRow& r, const ConvCfg& g, int B, const void* in, int in_ld,
                              int in_coff, void* out, int out_ld, int out_coff, const void* res, int res_ld,
@@ -251,6 +256,7 @@ static void fill_conv_params(int conv_elem_size, ConvParams& p, const ConvRow& r
     p.tiles_y = (p.Hout + g.TH - 1) / g.TH; p.tiles_x = (p.Wout + g.TW - 1) / g.TW;
     p.WN = g.WN;
     p.nt = g.threads;
+    p.pk_lin = pk_linear_map();
     p.act = r.kind == 0; p.out_f32 = out_f32 ? 1 : 0;
     p.deconv_c = deconv ? r.c2 : 0;
     p.swap_rb = swap_rb ? 1 : 0;
@@ -399,7 +405,7 @@ static int32_t forward_impl(vti_ctx* c, const uint8_t* input, int32_t B, int32_t
                 ConvParams q;
                 memset(&q, 0, sizeof q);
                 q.in = buf_ptr(c, op.in.buf, input, proto); q.B = B; q.Hin = ru.h_in; q.Win = ru.w_in; q.Hout = ru.h_in; q.Wout = ru.w_in;
-                q.Cin = ru.c1; q.in_ld = ib.C; q.in_coff = op.in.coff; q.Cout = g.gemm_n; q.act = 1; q.fold = 1;
+                q.Cin = ru.c1; q.in_ld = ib.C; q.in_coff = op.in.coff; q.Cout = g.gemm_n; q.act = 1; q.fold = 1; q.pk_lin = pk_linear_map();
                 q.TH = g.TH; q.TW = g.TW; q.tiles_y = (q.Hout + g.TH - 1) / g.TH; q.tiles_x = (q.Wout + g.TW - 1) / g.TW; q.WN = 4;
                 q.nchunks = g.nchunks; q.ntiles_n = g.ntiles_n;
                 q.pw_magic = (unsigned)((0x100000000ull + (unsigned)(g.TW + 2) - 1) / (unsigned)(g.TW + 2));

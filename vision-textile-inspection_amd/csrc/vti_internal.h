@@ -125,7 +125,7 @@ struct ConvParams {
     float* best;      // act2 == 2 (class scores into pred): also (max score, its first class) per anchor -> best[(b * out2_bstride + pixel) * 2], or null
     float dfl_stride;
     // persistent kernel (conv_pk.hip): tile count, workgroups along x, XCD-contiguous tile ranges, tensor sizes
-    int pk, pk_tiles, pk_wgs, pk_xcd, pk_depth, pk_wstat;
+    int pk, pk_tiles, pk_wgs, pk_xcd, pk_depth, pk_wstat, pk_lin /* 1: linear pixel -> column-tile map (A/B aid) */;
     unsigned in_bytes, out_bytes, res_bytes, out2_bytes;
     // conv1_pk: channels [0, up_C) come from in2 [B, Hout/2, Wout/2, in2_ld] at (y >> 1, x >> 1): the neck's Upsample + Concat folded into the loads
     const void* in2; int in2_ld, in2_coff, up_C; unsigned in2_bytes;
