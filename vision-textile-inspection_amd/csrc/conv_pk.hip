@@ -971,10 +971,23 @@ __global__ __launch_bounds__(512) void bneck_pk(const ConvParams p) {
     int tw1[BN_MREP1];                                      // T-image byte address of this lane's channel run
 #pragma unroll
     for (int m = 0; m < BN_MREP1; ++m) {
-        const int pp = (wm * BN_MREP1 + m) * 16 + (lane & 15);
-        v1[m] = pp < R1H * R1W;
-        const int pc = v1[m] ? pp : 0;
-        const int yy = (int)(((unsigned)pc * 2979u) >> 16), xx = pc - yy * R1W;      // pc / 22 for pc < 8192
+        // column tiles of the (TH + 2) x 22 region: a row's first 16 pixels, then blocks of 2 rows x its last 6 pixels (12 lanes) -- when
+        // these fit the waves' 7 tiles each (TH = 16, 12); otherwise the linear cut (whose row wraps are 2-way LDS conflicts: see conv3_pk)
+        const int ct = wm * BN_MREP1 + m, li = lane & 15;
+        const bool rowrun = !p.pk_lin && R1H + (R1H + 1) / 2 <= BN_MREP1 * (p.TH / PK_ROWS);
+        int yy, xx;
+        if (rowrun) {
+            const int r6 = (li * 43) >> 8;                                           // li / 6 for li < 16
+            yy = ct < R1H ? ct : 2 * (ct - R1H) + r6;
+            xx = ct < R1H ? li : 16 + li - 6 * r6;
+            v1[m] = ct < R1H || (li < 12 && yy < R1H);
+            if (!v1[m]) { yy = 0; xx = 0; }
+        } else {
+            const int pp = ct * 16 + li;
+            v1[m] = pp < R1H * R1W;
+            const int pc = v1[m] ? pp : 0;
+            yy = (int)(((unsigned)pc * 2979u) >> 16); xx = pc - yy * R1W;            // pc / 22 for pc < 8192
+        }
         r1y[m] = yy; r1x[m] = xx;
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) {
