@@ -27,7 +27,7 @@
  *    are a scatter of uint8 frames and a gather of detections + consumer reductions, done by the host shim with
  *    torch.distributed (backend "nccl" = RCCL over xGMI; vti_amd/dataparallel.py).  The library itself opens no communicator
  *    and exports no vti_dp_* entry points: there is no collective inside the model.
- *  - Tensor layouts (T = fp16 or fp32 per vti_desc.dtype):
+ *  - Tensor layouts (T = fp16 for VTI_F16, fp32 for VTI_F32 and VTI_H2):
  *      frames   u8  [B,H0,W0,3]           camera frames, any channel order (see swap_rb)
  *      input    u8  [B,H,W,3]             letterboxed frames (H,W multiples of 32)
  *      pred     f32 [B,A,4+nc+nm]         decoded head output, ANCHOR-MAJOR: Ultralytics' [B,4+nc+nm,A] transposed, so that
@@ -65,7 +65,11 @@ typedef enum {
     VTI_ERR_UNSUPPORTED = -6
 } vti_status;
 
-enum { VTI_F16 = 0, VTI_F32 = 1 };
+/* Storage type of weights and activations.  VTI_H2 = split-fp16: every element is the fp16 pair (hi, lo) of value * 16
+ * (22-23 significant bits) and every product runs on the fp16 matrix pipe (two 16x16x32 MFMAs per 16 channels, fp32
+ * accumulation): the results meet the reference tolerance (mask IoU >= 0.999, |d box| < 1e-3) like VTI_F32 at ~4x its matrix rate.
+ * proto is f32 for VTI_H2 and VTI_F32, fp16 for VTI_F16. */
+enum { VTI_F16 = 0, VTI_F32 = 1, VTI_H2 = 2 };
 enum { VTI_MASK_LOGIT = 0,     /* current Ultralytics: crop, bilinear upsample, > 0.0 */
        VTI_MASK_SIGMOID = 1 }; /* Ultralytics 8.0.x : sigmoid, crop, upsample, > 0.5  */
 enum { VTI_PACK_U8 = 0, VTI_PACK_BITS = 1 };
@@ -81,7 +85,7 @@ typedef struct {
     int32_t reg_max;   /* DFL bins, 16 */
     int32_t H, W;      /* letterboxed input size, multiples of 32 */
     int32_t max_batch; /* largest B any call will pass */
-    int32_t dtype;     /* VTI_F16 / VTI_F32: storage type of weights and activations */
+    int32_t dtype;     /* VTI_F16 / VTI_F32 / VTI_H2: storage type of weights and activations */
 } vti_desc;
 
 /* One row of the fused conv table (replaces walking model.model[*] of the unpickled net). */

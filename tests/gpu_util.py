@@ -19,7 +19,8 @@ def engine_and_oracle(scale, nc, H, W, B, dtype, seed=1, cls_bias=None, gain=1.7
     eng = vti_amd.Engine(scale, nc, H=H, W=W, max_batch=B, dtype=dtype)
     blob = vti_amd.random_weights(eng, seed=seed, cls_bias=cls_bias, gain=gain)
     eng.load_weights(blob, 0)
-    return eng, OracleModel(blob, H, W, mode=dtype), blob
+    # the h2 engine (split-fp16 pairs, ~22 bits) is held against the plain fp32 oracle
+    return eng, OracleModel(blob, H, W, mode="fp32" if dtype == "h2" else dtype), blob
 
 
 def frames_u8(B, H, W, seed=0):
@@ -28,7 +29,7 @@ def frames_u8(B, H, W, seed=0):
 
 def ref_conv(x_nhwc, w, b, k, s, kind, dtype, res=None, act=None):
     """torch-CPU reference of one engine conv on NHWC float input; fp16 mode rounds operands and result."""
-    q = (lambda t: t.half().float()) if dtype == "fp16" else (lambda t: t)
+    q = (lambda t: t.half().float()) if dtype == "fp16" else (lambda t: t)      # fp32 and h2: no operand rounding
     x = q(torch.as_tensor(x_nhwc).float()).permute(0, 3, 1, 2)
     w = q(torch.as_tensor(w).float())
     b = torch.as_tensor(b).float()

@@ -14,6 +14,20 @@ from gpu_util import need_gpu, ref_conv
 pytestmark = pytest.mark.gpu
 
 
+def _to_dev(a, dtype):
+    """host float array -> device tensor in the engine's storage type (h2: split-fp16 pairs carried as f32 bits)."""
+    import vti_amd
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype == "h2":
+        return vti_amd.h2_encode(t).cuda()
+    return t.to(torch.float16 if dtype == "fp16" else torch.float32).cuda()
+
+
+def _to_host(t, dtype, out_f32=False):
+    import vti_amd
+    return vti_amd.h2_decode(t.cpu()) if (dtype == "h2" and not out_f32) else t.float().cpu()
+
+
 def _ints(rng, shape, lo, hi):
     return rng.integers(lo, hi + 1, shape).astype(np.float32)
 
@@ -50,7 +64,7 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("dtype", ["fp16", "fp32"])
+@pytest.mark.parametrize("dtype", ["fp16", "fp32", "h2"])
 @pytest.mark.parametrize("case", CASES, ids=lambda c: f"k{c[0]}s{c[1]}kind{c[2]}_{c[3]}to{c[4]}_{c[5]}x{c[6]}_wn{c[7][0]}n{c[7][1]}")
 def test_conv_exact_integers(case, dtype, monkeypatch):
     need_gpu()
@@ -66,20 +80,19 @@ def test_conv_exact_integers(case, dtype, monkeypatch):
     wshape = (c1, c2, k, k) if kind == 2 else (c2, c1, k, k)
     w = _ints(rng, wshape, -1, 1)
     b = _ints(rng, (c2,), -3, 3)
-    tdt = torch.float16 if dtype == "fp16" else torch.float32
-    xd = torch.from_numpy(x_full).to(tdt).cuda()
+    xd = _to_dev(x_full, dtype)
     Ho, Wo = (2 * H, 2 * W) if kind == 2 else ((H + 2 * (k // 2) - k) // s + 1, (W + 2 * (k // 2) - k) // s + 1)
     res = resd = None
     if ex.get("res"):
         res = _ints(rng, (B, Ho, Wo, c2), -4, 4)
-        resd = torch.from_numpy(res).to(tdt).cuda()
+        resd = _to_dev(res, dtype)
     out, _, cfg = vti_amd.debug_conv2d(xd, w, b, k, s, kind, dtype, res=resd, in_coff=in_coff, c1=c1,
                                        out_coff=ex.get("out_coff", 0), out_ld=ex.get("out_ld"),
                                        out_f32=ex.get("out_f32", False), waves_n=wn, nrep=nrep)
     torch.cuda.synchronize()
     ref = ref_conv(x, w, b, k, s, kind, dtype, res=res, act=False)
     oc = ex.get("out_coff", 0)
-    got = out.float().cpu()
+    got = _to_host(out, dtype, ex.get("out_f32", False))
     assert torch.equal(got[..., oc:oc + c2], ref), f"cfg={cfg} max|d|={(got[..., oc:oc + c2] - ref).abs().max()}"
     if k == 3 and s == 1 and W >= 20:
         assert cfg["pk"], cfg       # these shapes must exercise the persistent kernel
@@ -87,7 +100,7 @@ def test_conv_exact_integers(case, dtype, monkeypatch):
         assert (got[..., :oc] == 0).all() and (got[..., oc + c2:] == 0).all()
 
 
-@pytest.mark.parametrize("dtype,tol", [("fp16", 2e-3), ("fp32", 2e-6)])
+@pytest.mark.parametrize("dtype,tol", [("fp16", 2e-3), ("fp32", 2e-6), ("h2", 4e-6)])
 def test_conv_silu_random(dtype, tol):
     """Random operands + fused bias/SiLU/residual epilogue: within rounding of the CPU op."""
     need_gpu()
@@ -98,13 +111,11 @@ def test_conv_silu_random(dtype, tol):
     w = (rng.standard_normal((c2, c1, 3, 3)) / np.sqrt(9 * c1)).astype(np.float32)
     b = rng.standard_normal(c2).astype(np.float32) * 0.1
     res = rng.standard_normal((B, H, W, c2)).astype(np.float32)
-    tdt = torch.float16 if dtype == "fp16" else torch.float32
-    out, _, _ = vti_amd.debug_conv2d(torch.from_numpy(x).to(tdt).cuda(), w, b, 3, 1, 0, dtype,
-                                     res=torch.from_numpy(res).to(tdt).cuda())
+    out, _, _ = vti_amd.debug_conv2d(_to_dev(x, dtype), w, b, 3, 1, 0, dtype, res=_to_dev(res, dtype))
     ref = ref_conv(x, w, b, 3, 1, 0, dtype, res=res)
     if dtype == "fp16":
         ref = ref.half().float()
-    err = (out.float().cpu() - ref).abs().max().item()
+    err = (_to_host(out, dtype) - ref).abs().max().item()
     assert err < tol * max(1.0, ref.abs().max().item()), err
 
 
@@ -132,7 +143,7 @@ def test_conv3x3_silu_persistent(shape, wgs, monkeypatch):
     assert err < 2e-3 * max(1.0, ref.abs().max().item()), (err, cfg)
 
 
-@pytest.mark.parametrize("dtype,tol", [("fp16", 1e-3), ("fp32", 1e-6)])
+@pytest.mark.parametrize("dtype,tol", [("fp16", 1e-3), ("fp32", 1e-6), ("h2", 2e-6)])
 @pytest.mark.parametrize("swap", [False, True])
 def test_stem_conv_u8(dtype, tol, swap):
     """model.0: u8 HWC3 frame -> /255 -> 3x3 s2 conv (+ channel flip), ragged size."""
@@ -148,5 +159,5 @@ def test_stem_conv_u8(dtype, tol, swap):
     ref = ref_conv(xin, w, b, 3, 2, 0, dtype)
     if dtype == "fp16":
         ref = ref.half().float()
-    err = (out.float().cpu() - ref).abs().max().item()
+    err = (_to_host(out, dtype) - ref).abs().max().item()
     assert out.shape == (B, 23, 31, c2) and err < tol * max(1.0, ref.abs().max().item()), err

@@ -386,6 +386,7 @@ hipError_t launch_convfold(int dtype, const ConvParams& p, size_t lds_bytes, hip
     if (p.TH * p.TW > MREP * 16 || ((p.TH + 2) * (p.TW + 2) + 7) / 8 * 32 > 256 * 8 || p.Cout != 256 || !p.out2 || !p.fold)
         return hipErrorInvalidValue;
     if (dtype == VTI_F16) return launch_convfold_t<half_t>(p, grid, lds_bytes, st);
+    if (dtype == VTI_H2) return launch_convfold_t<h2_t>(p, grid, lds_bytes, st);
     return launch_convfold_t<float>(p, grid, lds_bytes, st);
 }
 
@@ -453,7 +454,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const ConvParams p) {
         }
         raw32[i] = v;
     }
-    lut[tid] = (T)((float)tid / 255.0f);
+    lut[tid] = to_T<T>((float)tid / 255.0f);
     __syncthreads();
 
     const int tile_px = p.TH * p.TW;
@@ -495,7 +496,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const ConvParams p) {
         for (int m = 0; m < MREP; ++m) {
             vec x;
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) x[j] = off[j] >= 0 ? lut[raw[rbase[m] + off[j]]] : (T)0;
+            for (int j = 0; j < VEC; ++j) vset<T>(x, j, off[j] >= 0 ? lut[raw[rbase[m] + off[j]]] : to_T<T>(0.f));
 #pragma unroll
             for (int n = 0; n < NREP; ++n) acc[m][n] = mma(w[n], x, acc[m][n]);
         }
@@ -539,7 +540,7 @@ __global__ __launch_bounds__(256) void stem_l1_kernel(const ConvParams p) {
     constexpr int VEC = Tr<T>::VEC, KC = Tr<T>::KC, ES = (int)sizeof(T);
     constexpr int NCH = 32 / KC;                        // stem K chunks (27 -> 32)
     constexpr int NS1 = sizeof(T) == 2 ? 5 : 9;         // layer-1 K steps
-    constexpr bool FAST = sizeof(T) == 2;
+    constexpr bool FAST = !Tr<T>::F32;
     constexpr int SL_PITCH = sl_pitch(ES);
     constexpr int CP_BYTES = (SL_RH * SL_PITCH * ES + 15) & ~15;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -652,7 +653,7 @@ __global__ __launch_bounds__(256) void stem_l1_kernel(const ConvParams p) {
                     *(half4*)o = hv;
                 } else {
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) o[k] = (float)((v >> (8 * k)) & 0xffu) / 255.0f;
+                    for (int k = 0; k < 4; ++k) o[k] = to_T<T>((float)((v >> (8 * k)) & 0xffu) / 255.0f);
                 }
             }
         }
@@ -661,7 +662,7 @@ __global__ __launch_bounds__(256) void stem_l1_kernel(const ConvParams p) {
     for (int i = tid; i < SL_RH * ((SL_PITCH - 4 * SL_RWD) / 4); i += 256) {
         const int ry = i / ((SL_PITCH - 4 * SL_RWD) / 4), c4 = i - ry * ((SL_PITCH - 4 * SL_RWD) / 4);
         T* o = cp + (size_t)ry * SL_PITCH + 4 * SL_RWD + 4 * c4;
-        o[0] = (T)0; o[1] = (T)0; o[2] = (T)0; o[3] = (T)0;
+        o[0] = to_T<T>(0.f); o[1] = to_T<T>(0.f); o[2] = to_T<T>(0.f); o[3] = to_T<T>(0.f);
     }
     __syncthreads();
     VTI_STAMP(1);
@@ -701,7 +702,7 @@ __global__ __launch_bounds__(256) void stem_l1_kernel(const ConvParams p) {
 #pragma unroll
             for (int pp = 0; pp < 4; ++pp) {
                 const int sx = 4 * J + pp;
-                f32x4 v = silu4<FAST>(acc[pp] + bias4);
+                f32x4 v = silu4<FAST>(acc_bias<T>(acc[pp], bias4, p.alpha0));
                 if (!(row_in && (unsigned)(sx0 + sx) < (unsigned)Ws)) v = (f32x4){0.f, 0.f, 0.f, 0.f};     // layer 1's zero padding
                 if (wvalid && sx < SL_SW) {
                     T* o = (T*)(sout + ((size_t)(sy * SL_SW + sx) * 16 + g * 4) * ES);
@@ -711,7 +712,7 @@ __global__ __launch_bounds__(256) void stem_l1_kernel(const ConvParams p) {
                         for (int j = 0; j < 4; ++j) hv[j] = (half_t)v[j];
                         *(half4*)o = hv;
                     } else {
-                        *(f32x4*)o = v;
+                        *(u32x4*)o = pack4<T>(v);
                     }
                 }
             }
@@ -770,6 +771,15 @@ hipError_t launch_stem_l1(int dtype, const ConvParams& p, hipStream_t st) {
             attr16 = true;
         }
         hipLaunchKernelGGL(stem_l1_kernel<half_t>, grid, dim3(256), lds, st, p);
+    } else if (dtype == VTI_H2) {
+        static bool attrh2_dev[kMaxDevices] = {};
+        bool& attrh2 = attrh2_dev[current_device_slot()];
+        if (!attrh2) {
+            hipError_t e = hipFuncSetAttribute((const void*)stem_l1_kernel<h2_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+            attrh2 = true;
+        }
+        hipLaunchKernelGGL(stem_l1_kernel<h2_t>, grid, dim3(256), lds, st, p);
     } else {
         static bool attr_done_dev[kMaxDevices] = {};
         bool& attr_done = attr_done_dev[current_device_slot()];
@@ -868,6 +878,7 @@ hipError_t launch_conv(int dtype, int ks, int stride, int nrep, int mode, const 
     if ((p.nt != 256 && p.nt != 512) || (p.nt == 512 && p.ntiles2 == 0)) return hipErrorInvalidValue;     // 512 threads: fused towers only
     if (p.TH * p.TW > (nwaves / p.WN) * MREP * 16 || (p.WN != 1 && p.WN != 2 && p.WN != 4)) return hipErrorInvalidValue;
     if (dtype == VTI_F16) return launch_t<half_t>(ks, stride, nrep, mode, p, grid, lds_bytes, st);
+    if (dtype == VTI_H2) return launch_t<h2_t>(ks, stride, nrep, mode, p, grid, lds_bytes, st);
     return launch_t<float>(ks, stride, nrep, mode, p, grid, lds_bytes, st);
 }
 

@@ -10,9 +10,58 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// ---- h2: split-fp16 storage (VTI_H2).  One element is 4 bytes: the fp16 pair (hi | lo << 16) with hi = fp16(v * H2_SX),
+// lo = fp16(v * H2_SX - hi): 22-23 significant bits in fp16 MFMA operands.  Every layout (64-byte pixel slots of 16 channels,
+// 1-KiB weight fragments of 4 channels x 16 B per lane, KC = 16) is the fp32 engine's, so the data movement of every kernel is
+// shared with it; what differs is the matrix instruction -- two 16x16x32 f16 MFMAs per 16 channels instead of four 16x16x4 f32
+// ones (4x the rate) -- and the encode in the epilogues.  Weights are stored as pairs of w * SW (SW a per-conv power of two that
+// puts max|w| in [2^13, 2^14): lo parts stay normal numbers); the epilogue multiplies the accumulator by alpha = 1 / (SW * H2_SX).
+// Why not plain fp16: profiles/r03_precision_ablation.txt -- the north-star gate (mask IoU >= 0.999, |d box| < 1e-3, same kept set)
+// needs >= 20 significant bits in EVERY stored tensor and weight of these networks.
+struct h2_t { unsigned u; };
+struct h2x4 { u32x4 u; };
+constexpr float H2_SX = 16.0f;          // activation scale: |v| < 4094 representable, lo parts normal down to |v| ~ 8e-3
+
 template <typename T> struct Tr;
-template <> struct Tr<half_t> { typedef half8 vec; static constexpr int VEC = 8, KC = 32; };
-template <> struct Tr<float> { typedef f32x4 vec; static constexpr int VEC = 4, KC = 16; };
+template <> struct Tr<half_t> { typedef half8 vec; static constexpr int VEC = 8, KC = 32; static constexpr bool H16 = true, F32 = false, H2 = false; };
+template <> struct Tr<float> { typedef f32x4 vec; static constexpr int VEC = 4, KC = 16; static constexpr bool H16 = false, F32 = true, H2 = false; };
+template <> struct Tr<h2_t> { typedef h2x4 vec; static constexpr int VEC = 4, KC = 16; static constexpr bool H16 = false, F32 = false, H2 = true; };
+
+__device__ __forceinline__ unsigned h2_enc(float v) {
+    const float s = v * H2_SX;
+    const half_t hi = (half_t)s;
+    const half_t lo = (half_t)(s - (float)hi);
+    return (unsigned)__builtin_bit_cast(unsigned short, hi) | ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
+}
+__device__ __forceinline__ float h2_dec(unsigned u) {
+    const half_t hi = __builtin_bit_cast(half_t, (unsigned short)(u & 0xffffu)), lo = __builtin_bit_cast(half_t, (unsigned short)(u >> 16));
+    return ((float)hi + (float)lo) * (1.0f / H2_SX);      // hi + lo is exact in f32 (<= 24 significant bits)
+}
+// one element from a float; element j of an operand vector
+template <typename T> __device__ __forceinline__ T to_T(float v) {
+    if constexpr (Tr<T>::H2) return h2_t{h2_enc(v)};
+    else return (T)v;
+}
+template <typename T> __device__ __forceinline__ void vset(typename Tr<T>::vec& x, int j, T e) {
+    if constexpr (Tr<T>::H2) x.u[j] = e.u;
+    else x[j] = e;
+}
+// 4 channels of a 4-byte element type <-> f32x4 (float: a bit cast)
+template <typename T> __device__ __forceinline__ u32x4 pack4(f32x4 v) {
+    if constexpr (Tr<T>::H2) return (u32x4){h2_enc(v[0]), h2_enc(v[1]), h2_enc(v[2]), h2_enc(v[3])};
+    else return __builtin_bit_cast(u32x4, v);
+}
+template <typename T> __device__ __forceinline__ f32x4 unpack4(u32x4 u) {
+    if constexpr (Tr<T>::H2) return (f32x4){h2_dec(u[0]), h2_dec(u[1]), h2_dec(u[2]), h2_dec(u[3])};
+    else return __builtin_bit_cast(f32x4, u);
+}
+// accumulator -> pre-activation: h2 accumulators carry the weight and activation scales (alpha = 1 / (SW * H2_SX))
+template <typename T> __device__ __forceinline__ f32x4 acc_bias(f32x4 acc, f32x4 bias, float alpha) {
+    if constexpr (Tr<T>::H2) return acc * (f32x4){alpha, alpha, alpha, alpha} + bias;
+    else return acc + bias;
+}
 
 __device__ __forceinline__ f32x4 mma(half8 w, half8 x, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(w, x, c, 0, 0, 0);
@@ -24,6 +73,22 @@ __device__ __forceinline__ f32x4 mma(f32x4 w, f32x4 x, f32x4 c) {
     c = __builtin_amdgcn_mfma_f32_16x16x4f32(w[1], x[1], c, 0, 0, 0);
     c = __builtin_amdgcn_mfma_f32_16x16x4f32(w[2], x[2], c, 0, 0, 0);
     c = __builtin_amdgcn_mfma_f32_16x16x4f32(w[3], x[3], c, 0, 0, 0);
+    return c;
+}
+
+// h2: the weight fragment holds (hi | lo << 16) pairs of 4 channels; the pixel fragment the same.  With WH = the hi halves
+// duplicated into both halves of each dword and WL = the lo halves duplicated,
+//   mfma(WH, X) = sum wh * (xh + xl),  mfma(WL, X) = sum wl * (xh + xl):  all four partial products, fp32 accumulation.
+__device__ __forceinline__ f32x4 mma(h2x4 w, h2x4 x, f32x4 c) {
+    u32x4 wh, wl;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        wh[i] = __builtin_amdgcn_perm(w.u[i], w.u[i], 0x01000100u);
+        wl[i] = __builtin_amdgcn_perm(w.u[i], w.u[i], 0x03020302u);
+    }
+    const half8 xv = __builtin_bit_cast(half8, x.u);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, wh), xv, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, wl), xv, c, 0, 0, 0);
     return c;
 }
 
@@ -84,7 +149,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc)[
                                               int lane) {
     // Bias (and the residual of a whole pixel) are loaded up front: a load inside the store loop would make
     // every block wait on vmcnt(0), i.e. on all earlier STORES as well.
-    constexpr bool FAST = sizeof(T) == 2;
+    constexpr bool FAST = !Tr<T>::F32;
     const int crun = (nt0 + wn * NREP) * 16 + (lane >> 4) * 4 * NREP;
     f32x4 bias_r[NREP];
 #pragma unroll
@@ -112,7 +177,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc)[
 #pragma unroll
                             for (int j = 0; j < 4; ++j) res_r[n][j] = (float)r[j];
                         } else {
-                            res_r[n] = *(const f32x4*)(rp + 4 * n);
+                            res_r[n] = unpack4<T>(*(const u32x4*)(rp + 4 * n));
                         }
                     }
                 }
@@ -120,7 +185,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc)[
             f32x4 v[NREP];
 #pragma unroll
             for (int n = 0; n < NREP; ++n) {
-                v[n] = acc[m][n] + bias_r[n];
+                v[n] = acc_bias<T>(acc[m][n], bias_r[n], p.alpha);
                 if (p.act) v[n] = silu4<FAST>(v[n]);
                 if (has_res) v[n] += res_r[n];
             }
@@ -153,7 +218,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc)[
             } else {
 #pragma unroll
                 for (int n = 0; n < NREP; ++n)
-                    if (crun + 4 * n < p.Cout) *(f32x4*)(op + 4 * n) = v[n];
+                    if (crun + 4 * n < p.Cout) *(u32x4*)(op + 4 * n) = pack4<T>(v[n]);
             }
         }
         return;
@@ -191,7 +256,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc)[
         for (int n = 0; n < NREP; ++n) {
             const int cout0 = crun + 4 * n;
             if (cout0 >= p.Cout) continue;
-            f32x4 v = acc[m][n] + bias_r[n];
+            f32x4 v = acc_bias<T>(acc[m][n], bias_r[n], p.alpha);
             if (p.act) v = silu4<FAST>(v);
             size_t opix;
             int co = cout0;
@@ -209,7 +274,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc)[
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] += (float)r[j];
                 } else {
-                    v += *(const f32x4*)rp;
+                    v += unpack4<T>(*(const u32x4*)rp);
                 }
             }
             const size_t o = opix * p.out_ld + p.out_coff + co;
@@ -218,11 +283,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc)[
                 for (int j = 0; j < 4; ++j) {
                     if (cout0 + j < p.Cout) {
                         if (p.out_f32) ((float*)p.out)[o + j] = v[j];
+                        else if constexpr (Tr<T>::H2) ((unsigned*)p.out)[o + j] = h2_enc(v[j]);
                         else ((T*)p.out)[o + j] = (T)v[j];
                     }
                 }
-            } else if (p.out_f32 || sizeof(T) == 4) {
+            } else if (p.out_f32 || Tr<T>::F32) {
                 *(f32x4*)((float*)p.out + o) = v;
+            } else if constexpr (Tr<T>::H2) {
+                *(u32x4*)((unsigned*)p.out + o) = pack4<T>(v);
             } else {
                 half4 hv;
 #pragma unroll
@@ -235,8 +303,6 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc)[
 
 // Loads are raw buffer loads: 32-bit per-piece offsets computed once per tile, a scalar offset per chunk,
 // and the hardware range check returns zeros for halo pixels outside the image (offset 0xFFFFFFFF).
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
 template <typename V> __device__ __forceinline__ V buf_load16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
     return __builtin_bit_cast(V, v);
@@ -282,7 +348,7 @@ __device__ __forceinline__ void conv_stage2(const ConvParams& p, f32x4 (&acc)[MR
     // of its 80 pixels).  silu(acc + bias) in fp16/fp32 IS the MFMA pixel operand of the next GEMM:
     // lane group g of cout tile n holds channels 16n+4g+j, and the stage-2 weights are packed with
     // exactly that K order (weights.cpp: pack_conv_stage2), so nothing moves between lanes or LDS.
-    constexpr bool FAST = sizeof(T) == 2;
+    constexpr bool FAST = !Tr<T>::F32;
     constexpr int KT = sizeof(T) == 2 ? (NREP + 1) / 2 : NREP;
     const __amdgpu_buffer_rsrc_t rsW2 = __builtin_amdgcn_make_buffer_rsrc(
         (void*)p.w2, 0, (int)(KT * p.ntiles2 * 1024), 0x00020000);
@@ -326,17 +392,20 @@ __device__ __forceinline__ void conv_stage2(const ConvParams& p, f32x4 (&acc)[MR
                     const int n1 = 2 * t2 + h;
                     f32x4 v = {0.f, 0.f, 0.f, 0.f};
                     if (n1 < NREP) {
-                        v = acc[m][n1 < NREP ? n1 : 0] + bias1[FOLD ? m : 0][n1 < NREP ? n1 : 0];
+                        v = acc_bias<T>(acc[m][n1 < NREP ? n1 : 0], bias1[FOLD ? m : 0][n1 < NREP ? n1 : 0], p.alpha);
                         if (p.act) v = silu4<FAST>(v);
                     }
 #pragma unroll
                     for (int j = 0; j < 4; ++j) x[h * 4 + j] = (T)v[j];
                 }
             } else {
-                f32x4 v = acc[m][t2] + bias1[FOLD ? m : 0][t2];
+                f32x4 v = acc_bias<T>(acc[m][t2], bias1[FOLD ? m : 0][t2], p.alpha);
                 if (p.act) v = silu4<FAST>(v);
+                if constexpr (Tr<T>::H2) x.u = pack4<T>(v);
+                else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) x[j] = v[j];
+                    for (int j = 0; j < 4; ++j) x[j] = v[j];
+                }
             }
 #pragma unroll
             for (int n = 0; n < NREP2; ++n) acc2[m][n] = mma(w2[n], x, acc2[m][n]);
@@ -367,7 +436,7 @@ __device__ __forceinline__ void conv_stage2(const ConvParams& p, f32x4 (&acc)[MR
                 float d4[4];
 #pragma unroll
                 for (int n = 0; n < 4; ++n) {
-                    const f32x4 v = acc2[m][n] + bias2[n];
+                    const f32x4 v = acc_bias<T>(acc2[m][n], bias2[n], p.alpha2);
                     float mx = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
                     mx = fmaxf(mx, __shfl_xor(mx, 16));
                     mx = fmaxf(mx, __shfl_xor(mx, 32));
@@ -404,7 +473,7 @@ __device__ __forceinline__ void conv_stage2(const ConvParams& p, f32x4 (&acc)[MR
 #pragma unroll
                 for (int n = 0; n < NREP2; n += 2) {
                     if (crun2 + 4 * n >= p.Cout2) continue;
-                    f32x4 v0 = acc2[m][n] + bias2[n], v1 = acc2[m][n + 1] + bias2[n + 1];
+                    f32x4 v0 = acc_bias<T>(acc2[m][n], bias2[n], p.alpha2), v1 = acc_bias<T>(acc2[m][n + 1], bias2[n + 1], p.alpha2);
                     if (p.act2 == 1) { v0 = silu4<FAST>(v0); v1 = silu4<FAST>(v1); }
                     half8 hv;
 #pragma unroll
@@ -431,7 +500,7 @@ __device__ __forceinline__ void conv_stage2(const ConvParams& p, f32x4 (&acc)[MR
         for (int n = 0; n < NREP2; ++n) {
             const int cout0 = crun2 + cstep2 * n;
             if (cout0 >= p.Cout2) continue;
-            f32x4 v = acc2[m][n] + bias2[n];
+            f32x4 v = acc_bias<T>(acc2[m][n], bias2[n], p.alpha2);
             if (p.act2 == 1) v = silu4<FAST>(v);
             else if (p.act2 == 2) {         // class scores: sigmoid (exact in the fp32 parity engine, hw-rate ~1 ulp f32 in fp16)
 #pragma unroll
@@ -458,11 +527,14 @@ __device__ __forceinline__ void conv_stage2(const ConvParams& p, f32x4 (&acc)[MR
                 for (int j = 0; j < 4; ++j) {
                     if (cout0 + j < p.Cout2) {
                         if (p.out2_f32) ((float*)p.out2)[o + j] = v[j];
+                        else if constexpr (Tr<T>::H2) ((unsigned*)p.out2)[o + j] = h2_enc(v[j]);
                         else ((T*)p.out2)[o + j] = (T)v[j];
                     }
                 }
-            } else if (p.out2_f32 || sizeof(T) == 4) {
+            } else if (p.out2_f32 || Tr<T>::F32) {
                 *(f32x4*)((float*)p.out2 + o) = v;
+            } else if constexpr (Tr<T>::H2) {
+                *(u32x4*)((unsigned*)p.out2 + o) = pack4<T>(v);
             } else {
                 half4 hv;
 #pragma unroll

@@ -125,7 +125,7 @@ __global__ __launch_bounds__(512) void conv3_pk(const ConvParams p) {
     static_assert(S == 1 || (S == 2 && !FOLD && NREP2 == 0), "stride 2: plain epilogue only");
     constexpr int WCHUNK = NTB * TAPS * 1024;
     constexpr unsigned OOB = 0x80000000u;
-    constexpr bool FAST = sizeof(T) == 2;
+    constexpr bool FAST = !Tr<T>::F32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -382,13 +382,13 @@ __global__ __launch_bounds__(512) void conv3_pk(const ConvParams p) {
 #pragma unroll
                             for (int j = 0; j < 4; ++j) v[n][j] = (float)r[j];
                         } else {
-                            v[n] = buf_load16<f32x4>(rsR, cv ? rb + n * 16 : OOB, 0u);
+                            v[n] = unpack4<T>(buf_load16<u32x4>(rsR, cv ? rb + n * 16 : OOB, 0u));
                         }
                     }
                 }
 #pragma unroll
                 for (int n = 0; n < NREP; ++n) {
-                    f32x4 a = acc[m][n] + bias_r[n];
+                    f32x4 a = acc_bias<T>(acc[m][n], bias_r[n], p.alpha);
                     if (p.act) a = silu4<FAST>(a);
                     if constexpr (has_res) v[n] += a; else v[n] = a;
                 }
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(512) void conv3_pk(const ConvParams p) {
 #pragma unroll
                     for (int n = 0; n < NREP; ++n) {
                         const bool cv = pv && crun + 4 * n < p.Cout;
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[n]), rsO, cv ? ob + n * 16 : OOB, 0u, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(pack4<T>(v[n]), rsO, cv ? ob + n * 16 : OOB, 0u, 0);
                     }
                 }
             }
@@ -473,7 +473,7 @@ __global__ __launch_bounds__(512) void conv1_pk(const ConvParams p) {
     constexpr int NTB = WN * NREP;
     constexpr int WCH = NTB * 1024;
     constexpr unsigned OOB = 0x80000000u;
-    constexpr bool FAST = sizeof(T) == 2;
+    constexpr bool FAST = !Tr<T>::F32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -634,7 +634,7 @@ __global__ __launch_bounds__(512) void conv1_pk(const ConvParams p) {
                 f32x4 v[NREP];
 #pragma unroll
                 for (int n = 0; n < NREP; ++n) {
-                    v[n] = acc[m][n] + bias_r[n];
+                    v[n] = acc_bias<T>(acc[m][n], bias_r[n], p.alpha);
                     if (p.act) v[n] = silu4<FAST>(v[n]);
                 }
                 if constexpr (sizeof(T) == 2 && NREP % 2 == 0) {
@@ -660,7 +660,7 @@ __global__ __launch_bounds__(512) void conv1_pk(const ConvParams p) {
 #pragma unroll
                     for (int n = 0; n < NREP; ++n) {
                         const bool cv = pv && crun + 4 * n < p.Cout;
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[n]), rsO, cv ? ob + n * 16 : OOB, 0u, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(pack4<T>(v[n]), rsO, cv ? ob + n * 16 : OOB, 0u, 0);
                     }
                 }
             }
@@ -762,6 +762,7 @@ hipError_t launch_conv1_pk(int dtype, int nrep, const ConvParams& p, size_t lds_
     const int threads = 2 * p.TH * p.WN * 64;
     dim3 grid((unsigned)p.pk_wgs, (unsigned)(p.ntiles_n / NTB));
     if (dtype == VTI_F16) return launch_pk1_t<half_t>(nrep, p, grid, threads, lds_bytes, st);
+    if (dtype == VTI_H2) return launch_pk1_t<h2_t>(nrep, p, grid, threads, lds_bytes, st);
     return launch_pk1_t<float>(nrep, p, grid, threads, lds_bytes, st);
 }
 
@@ -785,6 +786,7 @@ hipError_t launch_conv_pk_fold(int dtype, const ConvParams& p, size_t lds_bytes,
 #define VTI_FP(N2)                                                                                              \
     if (p.ntiles2 == N2) {                                                                                      \
         if (dtype == VTI_F16) return launch_pk_one<half_t, 4, 4, N2, true>(p, grid, 512, lds_bytes, st);        \
+        if (dtype == VTI_H2) return launch_pk_one<h2_t, 4, 4, N2, true>(p, grid, 512, lds_bytes, st);           \
         return launch_pk_one<float, 4, 4, N2, true>(p, grid, 512, lds_bytes, st);                               \
     }
     VTI_FP(1) VTI_FP(2) VTI_FP(4)
@@ -805,6 +807,7 @@ hipError_t launch_conv_pk2(int dtype, int nrep, const ConvParams& p, size_t lds_
 #define VTI_L2(N, W)                                                                                           \
     if (nrep == N && p.WN == W) {                                                                              \
         if (dtype == VTI_F16) return launch_pk_one<half_t, N, W, 0, false, 2>(p, grid, threads, lds_bytes, st); \
+        if (dtype == VTI_H2) return launch_pk_one<h2_t, N, W, 0, false, 2>(p, grid, threads, lds_bytes, st);    \
         return launch_pk_one<float, N, W, 0, false, 2>(p, grid, threads, lds_bytes, st);                        \
     }
     VTI_L2(1, 4) VTI_L2(2, 2) VTI_L2(4, 1) VTI_L2(2, 1) VTI_L2(1, 2)
@@ -823,6 +826,7 @@ hipError_t launch_conv_pk(int dtype, int nrep, const ConvParams& p, size_t lds_b
     const int threads = 2 * (p.TH / PK_ROWS) * p.WN * 64;   // compute waves + as many loader waves
     dim3 grid((unsigned)p.pk_wgs, (unsigned)(p.ntiles_n / NTB));
     if (dtype == VTI_F16) return launch_pk_t<half_t>(nrep, p, grid, threads, lds_bytes, st);
+    if (dtype == VTI_H2) return launch_pk_t<h2_t>(nrep, p, grid, threads, lds_bytes, st);
     return launch_pk_t<float>(nrep, p, grid, threads, lds_bytes, st);
 }
 
@@ -876,7 +880,7 @@ __global__ __launch_bounds__(512) void bneck_pk(const ConvParams p) {
     constexpr int VEC = Tr<T>::VEC, ES = (int)sizeof(T);
     constexpr int TAPS = 9, R1W = PK_TW + 2;
     constexpr unsigned OOB = 0x80000000u;
-    constexpr bool FAST = sizeof(T) == 2;
+    constexpr bool FAST = !Tr<T>::F32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
@@ -1090,7 +1094,7 @@ __global__ __launch_bounds__(512) void bneck_pk(const ConvParams p) {
                 f32x4 v[NREP];
 #pragma unroll
                 for (int n = 0; n < NREP; ++n) {
-                    v[n] = silu4<FAST>(acc[m][n] + b1r[n]);
+                    v[n] = silu4<FAST>(acc_bias<T>(acc[m][n], b1r[n], p.alpha));
                     if (!inside) v[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 }
                 if (!v1[m]) continue;
@@ -1106,7 +1110,7 @@ __global__ __launch_bounds__(512) void bneck_pk(const ConvParams p) {
                     *(half4*)(smem + tw1[m]) = hv;
                 } else {
                     static_assert(sizeof(T) == 2 || NREP == 1, "fp32: one 16-channel chunk");
-                    *(f32x4*)(smem + tw1[m]) = v[0];
+                    *(u32x4*)(smem + tw1[m]) = pack4<T>(v[0]);
                 }
             }
         }
@@ -1157,7 +1161,7 @@ __global__ __launch_bounds__(512) void bneck_pk(const ConvParams p) {
                 const unsigned ob = (unsigned)((opix * p.out_ld + p.out_coff + crun) * ES);
                 f32x4 v[NREP];
 #pragma unroll
-                for (int n = 0; n < NREP; ++n) v[n] = silu4<FAST>(acc[m][n] + b2r[n]);
+                for (int n = 0; n < NREP; ++n) v[n] = silu4<FAST>(acc_bias<T>(acc[m][n], b2r[n], p.alpha2));
                 if (has_res) {                              // the shortcut: this pixel of the input patch, still in its stage
                     if constexpr (sizeof(T) == 2 && NREP == 2) {
                         const half8 r = *(const half8*)(sx + ra[m]);
@@ -1168,7 +1172,7 @@ __global__ __launch_bounds__(512) void bneck_pk(const ConvParams p) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) v[0][j] += (float)r[j];
                     } else {
-                        v[0] += *(const f32x4*)(sx + ra[m]);
+                        v[0] += unpack4<T>(*(const u32x4*)(sx + ra[m]));
                     }
                 }
                 if constexpr (TAIL) {
@@ -1202,7 +1206,7 @@ __global__ __launch_bounds__(512) void bneck_pk(const ConvParams p) {
                     for (int j = 0; j < 4; ++j) hv[j] = (half_t)v[0][j];
                     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hv), rsO, pv ? ob : OOB, 0u, 0);
                 } else {
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[0]), rsO, pv ? ob : OOB, 0u, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(pack4<T>(v[0]), rsO, pv ? ob : OOB, 0u, 0);
                 }
             }
         }
@@ -1247,6 +1251,7 @@ hipError_t launch_bneck_pk(int dtype, int nrep, const ConvParams& p, size_t lds_
         if (nrep == 1) return launch_bneck_one<half_t, 1>(p, grid, threads, lds_bytes, st);
         if (nrep == 2) return launch_bneck_one<half_t, 2>(p, grid, threads, lds_bytes, st);
     } else if (nrep == 1) {
+        if (dtype == VTI_H2) return launch_bneck_one<h2_t, 1>(p, grid, threads, lds_bytes, st);
         return launch_bneck_one<float, 1>(p, grid, threads, lds_bytes, st);
     }
     return hipErrorInvalidValue;

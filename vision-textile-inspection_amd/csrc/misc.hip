@@ -11,9 +11,37 @@ typedef _Float16 half_t;
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// h2 (VTI_H2, conv_dev.h): one element = the fp16 pair (hi | lo << 16) of value * 16; here it only has to be compared and copied
+struct h2e { unsigned u; };
+__device__ __forceinline__ float h2_val(unsigned u) {       // monotone in the element's value (the common scale does not matter)
+    return (float)__builtin_bit_cast(half_t, (unsigned short)(u & 0xffffu)) + (float)__builtin_bit_cast(half_t, (unsigned short)(u >> 16));
+}
+
 template <typename T> struct V16;
 template <> struct V16<half_t> { typedef half8 vec; static constexpr int N = 8; };
 template <> struct V16<float> { typedef f32x4 vec; static constexpr int N = 4; };
+template <> struct V16<h2e> { typedef u32x4 vec; static constexpr int N = 4; };
+
+__device__ __forceinline__ half8 vmax(half8 a, half8 b) { return __builtin_elementwise_max(a, b); }   // v_pk_max_f16
+__device__ __forceinline__ f32x4 vmax(f32x4 a, f32x4 b) { return __builtin_elementwise_max(a, b); }
+__device__ __forceinline__ u32x4 vmax(u32x4 a, u32x4 b) {       // h2 pairs: the pair with the larger decoded value, bits unchanged
+    u32x4 r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r[j] = h2_val(b[j]) > h2_val(a[j]) ? b[j] : a[j];
+    return r;
+}
+template <typename T> __device__ __forceinline__ typename V16<T>::vec vlowest() {
+    typename V16<T>::vec v;
+    if constexpr (sizeof(T) == 4 && !__is_same(T, float)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = 0xfc00u;             // hi = -inf, lo = +0
+    } else {
+#pragma unroll
+        for (int j = 0; j < V16<T>::N; ++j) v[j] = (T)(-INFINITY);
+    }
+    return v;
+}
 
 // ---- SPPF: three chained MaxPool2d(5,1,2) == max over 5x5 / 9x9 / 13x13 windows clipped to the
 // image (the implicit -inf padding makes chaining and direct windows identical).
@@ -30,9 +58,7 @@ __global__ __launch_bounds__(256) void sppf_pool_kernel(const PoolParams p) {
         const int y = (int)(r % p.H);
         const int b = (int)(r / p.H);
         const T* in = (const T*)p.in;
-        vec m5, m9, m13;
-#pragma unroll
-        for (int j = 0; j < N; ++j) m5[j] = m9[j] = m13[j] = (T)(-INFINITY);
+        vec m5 = vlowest<T>(), m9 = vlowest<T>(), m13 = vlowest<T>();
         for (int dy = -6; dy <= 6; ++dy) {
             const int yy = y + dy;
             if ((unsigned)yy >= (unsigned)p.H) continue;
@@ -41,12 +67,9 @@ __global__ __launch_bounds__(256) void sppf_pool_kernel(const PoolParams p) {
                 if ((unsigned)xx >= (unsigned)p.W) continue;
                 const vec v = *(const vec*)(in + ((size_t)(b * p.H + yy) * p.W + xx) * p.ld + p.in_coff + c * N);
                 const int ad = max(abs(dy), abs(dx));
-#pragma unroll
-                for (int j = 0; j < N; ++j) {
-                    m13[j] = v[j] > m13[j] ? v[j] : m13[j];
-                    if (ad <= 4) m9[j] = v[j] > m9[j] ? v[j] : m9[j];
-                    if (ad <= 2) m5[j] = v[j] > m5[j] ? v[j] : m5[j];
-                }
+                m13 = vmax(m13, v);
+                if (ad <= 4) m9 = vmax(m9, v);
+                if (ad <= 2) m5 = vmax(m5, v);
             }
         }
         T* o = (T*)p.out + ((size_t)(b * p.H + y) * p.W + x) * p.ld + p.out_coff + c * N;
@@ -101,7 +124,7 @@ __global__ __launch_bounds__(256) void sppf_pool_lds_kernel(const PoolParams p) 
                 const int xx = x + d;
                 if (d == 0 || (unsigned)xx >= (unsigned)p.W) continue;
                 const vec v = cur[(y * p.W + xx) * G + v_];
-                m = __builtin_elementwise_max(m, v);         // v_pk_max_f16 / v_max_f32: 4 instructions per 16-byte piece
+                m = vmax(m, v);                              // v_pk_max_f16 / v_max_f32: 4 instructions per 16-byte piece
             }
             tmp[i] = m;
         }
@@ -114,7 +137,7 @@ __global__ __launch_bounds__(256) void sppf_pool_lds_kernel(const PoolParams p) 
                 const int yy = y + d;
                 if (d == 0 || (unsigned)yy >= (unsigned)p.H) continue;
                 const vec v = tmp[(yy * p.W + x) * G + v_];
-                m = __builtin_elementwise_max(m, v);         // v_pk_max_f16 / v_max_f32: 4 instructions per 16-byte piece
+                m = vmax(m, v);                              // v_pk_max_f16 / v_max_f32: 4 instructions per 16-byte piece
             }
             cur[i] = m;
             *(vec*)(out + (size_t)pix * p.ld + pass * p.C + v_ * N) = m;
@@ -131,17 +154,20 @@ hipError_t launch_sppf_pool(int dtype, const PoolParams& p, hipStream_t st) {
     if (lds1 * 4 <= 64 * 1024 && p.C % (4 * N) == 0) {      // four 16-byte pieces per workgroup: 64-byte global segments
         const int grid = p.B * (p.C / (4 * N));
         if (dtype == VTI_F16) hipLaunchKernelGGL((sppf_pool_lds_kernel<half_t, 4>), dim3(grid), dim3(256), lds1 * 4, st, p);
+        else if (dtype == VTI_H2) hipLaunchKernelGGL((sppf_pool_lds_kernel<h2e, 4>), dim3(grid), dim3(256), lds1 * 4, st, p);
         else hipLaunchKernelGGL((sppf_pool_lds_kernel<float, 4>), dim3(grid), dim3(256), lds1 * 4, st, p);
         return hipGetLastError();
     }
     if (lds1 <= 64 * 1024) {
         const int grid = p.B * (p.C / N);
         if (dtype == VTI_F16) hipLaunchKernelGGL((sppf_pool_lds_kernel<half_t, 1>), dim3(grid), dim3(256), lds1, st, p);
+        else if (dtype == VTI_H2) hipLaunchKernelGGL((sppf_pool_lds_kernel<h2e, 1>), dim3(grid), dim3(256), lds1, st, p);
         else hipLaunchKernelGGL((sppf_pool_lds_kernel<float, 1>), dim3(grid), dim3(256), lds1, st, p);
         return hipGetLastError();
     }
     const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     if (dtype == VTI_F16) hipLaunchKernelGGL(sppf_pool_kernel<half_t>, dim3(grid), dim3(256), 0, st, p);
+    else if (dtype == VTI_H2) hipLaunchKernelGGL(sppf_pool_kernel<h2e>, dim3(grid), dim3(256), 0, st, p);
     else hipLaunchKernelGGL(sppf_pool_kernel<float>, dim3(grid), dim3(256), 0, st, p);
     return hipGetLastError();
 }
@@ -322,7 +348,8 @@ __global__ void debug_nchw_kernel(const T* src, int B, int H, int W, int C, int 
         const int y = (int)(r % H); r /= H;
         const int c = (int)(r % C);
         const int b = (int)(r / C);
-        dst[i] = (float)src[((size_t)(b * H + y) * W + x) * ld + coff + c];
+        if constexpr (sizeof(T) == 4 && !__is_same(T, float)) dst[i] = h2_val(src[((size_t)(b * H + y) * W + x) * ld + coff + c].u) * (1.0f / 16.0f);
+        else dst[i] = (float)src[((size_t)(b * H + y) * W + x) * ld + coff + c];
     }
 }
 
@@ -331,7 +358,8 @@ hipError_t launch_debug_nchw(int elem_is_f32, const void* src, int B, int H, int
     const long total = (long)B * C * H * W;
     if (total == 0) return hipSuccess;
     const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    if (elem_is_f32) hipLaunchKernelGGL(debug_nchw_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)src, B, H, W, C, ld, coff, dst);
+    if (elem_is_f32 == 2) hipLaunchKernelGGL(debug_nchw_kernel<h2e>, dim3(grid), dim3(256), 0, st, (const h2e*)src, B, H, W, C, ld, coff, dst);
+    else if (elem_is_f32) hipLaunchKernelGGL(debug_nchw_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)src, B, H, W, C, ld, coff, dst);
     else hipLaunchKernelGGL(debug_nchw_kernel<half_t>, dim3(grid), dim3(256), 0, st, (const half_t*)src, B, H, W, C, ld, coff, dst);
     return hipGetLastError();
 }

@@ -337,7 +337,7 @@ std::string Plan::build(const vti_desc& d) {
     if (d.reg_max != 16) return "only reg_max=16 is supported";
     if (d.H < 32 || d.W < 32 || d.H % 32 || d.W % 32) return "H and W must be positive multiples of 32";
     if (d.max_batch < 1) return "max_batch must be >= 1";
-    if (d.dtype != VTI_F16 && d.dtype != VTI_F32) return "dtype must be VTI_F16 or VTI_F32";
+    if (d.dtype != VTI_F16 && d.dtype != VTI_F32 && d.dtype != VTI_H2) return "dtype must be VTI_F16, VTI_F32 or VTI_H2";
     esize = d.dtype == VTI_F16 ? 2 : 4;
 
     auto ch = [&](int c) { return make_divisible(std::min(c, sc->maxc) * sc->width, 8); };
@@ -437,11 +437,13 @@ std::string Plan::build(const vti_desc& d) {
     b.lane = 1;
     {
         const int pc1 = b.new_buf(npr, H / 8, W / 8), pup = b.new_buf(npr, H / 4, W / 4);
-        const int pc2 = b.new_buf(npr, H / 4, W / 4), pout = b.new_buf(d.nm, H / 4, W / 4);
+        // the caller's proto is T for the fp16 / fp32 engines and f32 for the h2 engine (its pairs are an internal storage format)
+        const bool proto_f32 = d.dtype == VTI_H2;
+        const int pc2 = b.new_buf(npr, H / 4, W / 4), pout = b.new_buf(d.nm, H / 4, W / 4, proto_f32 ? EL_F32 : EL_T);
         b.conv("model.22.proto.cv1", b.whole(P3), b.whole(pc1), 3, 1, 0);
         b.conv("model.22.proto.upsample", b.whole(pc1), b.whole(pup), 2, 2, 2);
         b.conv("model.22.proto.cv2", b.whole(pup), b.whole(pc2), 3, 1, 0);
-        b.conv("model.22.proto.cv3", b.whole(pc2), b.whole(pout), 1, 1, 0);
+        b.conv("model.22.proto.cv3", b.whole(pc2), b.whole(pout), 1, 1, 0, proto_f32);
         proto_buf_c = pout;   // replaced by the caller's proto pointer at run time
     }
     {   // final op order: lane 0 carries backbone + neck (+ the P5 head); side lanes fork off it
@@ -650,7 +652,7 @@ std::string Plan::build(const vti_desc& d) {
             int nbox = 0;
             for (Op& op : ops)
                 if (op.kind == OP_CONV && op.fused >= 0 && convs[op.fused].name.rfind("model.22.cv2.", 0) == 0 && convs[op.fused].c2 == 64) ++nbox;
-            dfl_fused = nbox == 3 && d.dtype == VTI_F16 && d.reg_max == 16 && !(nd && nd[0] == '1');
+            dfl_fused = nbox == 3 && d.dtype != VTI_F32 && d.reg_max == 16 && !(nd && nd[0] == '1');
             if (dfl_fused) {
                 for (Op& op : ops) {
                     if (op.kind != OP_CONV || op.fused < 0 || convs[op.fused].name.rfind("model.22.cv2.", 0) != 0) continue;

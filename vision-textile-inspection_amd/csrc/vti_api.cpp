@@ -22,6 +22,7 @@ struct vti_ctx {
     int device = -1;
     void* d_wpk = nullptr;     // packed weights (device)
     float* d_bias = nullptr;   // biases (device)
+    std::vector<float> alpha;  // per conv: accumulator scale of its packed weights (VTI_H2; 1 otherwise)
     char* ws = nullptr;        // caller-owned workspace
     size_t ws_bytes = 0;
     size_t act_bytes = 0;      // activations part; NMS scratch follows
@@ -156,7 +157,7 @@ int32_t vti_load_weights(vti_ctx* c, const void* blob, size_t nbytes, int32_t de
     std::vector<uint8_t> wpk;
     std::vector<float> bias;
     std::string e;
-    try { e = pack_weights(c->plan, blob, nbytes, wpk, bias); } catch (const std::exception& ex) { e = ex.what(); }
+    try { e = pack_weights(c->plan, blob, nbytes, wpk, bias, c->alpha); } catch (const std::exception& ex) { e = ex.what(); }
     if (!e.empty()) return fail(c, VTI_ERR_WEIGHTS, e);
     VTI_HIP(c, hipSetDevice(device), "hipSetDevice");
     if (c->d_wpk) { (void)hipFree(c->d_wpk); c->d_wpk = nullptr; }
@@ -365,6 +366,7 @@ static int32_t forward_impl(vti_ctx* c, const uint8_t* input, int32_t B, int32_t
                 q.out = buf_ptr(c, op.out2.buf, input, proto); q.out_ld = o1.C; q.out_coff = op.out2.coff;
                 q.wpk = (const char*)c->d_wpk + g.wpk_off2; q.bias = c->d_bias + g.bias_off2;     // layer 1
                 q.w0 = (const char*)c->d_wpk + g.wpk_off; q.bias0 = c->d_bias + g.bias_off;       // stem
+                q.alpha = c->alpha[op.fused_l1]; q.alpha0 = c->alpha[op.conv]; q.alpha2 = op.fused >= 0 ? c->alpha[op.fused] : 1.f;
                 if (op.fused >= 0) {    // + the 1x1 conv after layer 1: layer 1 itself is not stored (out2 = that conv's view)
                     q.out = nullptr;
                     q.w2 = (const char*)c->d_wpk + g.wpk_off3; q.bias2 = c->d_bias + g.bias_off3;
@@ -412,11 +414,13 @@ static int32_t forward_impl(vti_ctx* c, const uint8_t* input, int32_t B, int32_t
                 q.tw_magic = (unsigned)((0x100000000ull + (unsigned)g.TW - 1) / (unsigned)g.TW);
                 q.wpk = (const char*)c->d_wpk + g.wpk_off; q.bias = c->d_bias + g.bias_off; q.wpk_bytes = (unsigned)packed_fold_bytes(g);
                 q.w2 = (const char*)c->d_wpk + g.wpk_off2; q.bias2 = c->d_bias + g.bias_off2;
+                q.alpha = c->alpha[op.conv]; q.alpha2 = c->alpha[op.fused]; q.alpha0 = 1.f;
                 q.out2 = buf_ptr(c, op.out2.buf, input, proto);
                 q.Cout2 = g.gemm_n2; q.ntiles2 = g.ntiles2; q.out2_ld = o2.C; q.out2_coff = op.out2.coff;
                 q.act2 = P.convs[op.fused].kind == 0; q.out2_f32 = op.out2_f32 ? 1 : 0;
                 q.scalar_store2 = (g.gemm_n2 % 4 || o2.C % 4 || op.out2.coff % 4) ? 1 : 0;
                 q.out2_bstride = 4 * q.Hout * q.Wout;
+                q.nat2 = op.nat2;           // f32 proto (h2 engine): stage-2 weights are packed with natural rows
                 if (g.pk) {             // persistent schedule: composed weights resident in LDS, tiles walked per XCD
                     q.pk = 1; q.pk_depth = g.pk_depth; q.in_bytes = (unsigned)((size_t)B * q.Hin * q.Win * q.in_ld * P.esize);
                     q.pk_tiles = B * q.tiles_y * q.tiles_x;
@@ -437,6 +441,8 @@ static int32_t forward_impl(vti_ctx* c, const uint8_t* input, int32_t B, int32_t
                              op.has_res ? buf_ptr(c, op.res.buf, input, proto) : nullptr,
                              op.has_res ? P.bufs[op.res.buf].C : 0, op.res.coff,
                              (const char*)c->d_wpk + g.wpk_off, c->d_bias + g.bias_off, op.out_f32, swap_rb);
+            p.alpha = c->alpha[op.conv]; p.alpha0 = 1.f;
+            p.alpha2 = op.fused >= 0 ? c->alpha[op.fused] : op.pair >= 0 ? c->alpha[op.pair] : 1.f;
             if (op.fused >= 0) {
                 const Buf& o2 = P.bufs[op.out2.buf];
                 p.w2 = (const char*)c->d_wpk + g.wpk_off2;
@@ -697,7 +703,8 @@ int32_t vti_debug_conv_output(vti_ctx* c, int32_t i, int32_t B, float* out, void
     const Buf& b = c->plan.bufs[v.buf];
     const void* src = buf_ptr(c, v.buf, c->last_input, c->last_proto);
     if (!src) return fail(c, VTI_ERR_STATE, "vti_debug_conv_output: run vti_forward first");
-    const int is_f32 = (b.elem == EL_F32) || (b.elem == EL_T && c->plan.desc.dtype == VTI_F32);
+    const int is_f32 = (b.elem == EL_F32 || (b.elem == EL_T && c->plan.desc.dtype == VTI_F32)) ? 1
+                       : (b.elem == EL_T && c->plan.desc.dtype == VTI_H2) ? 2 : 0;      // 2: h2 pairs
     VTI_HIP(c, launch_debug_nchw(is_f32, src, B, b.H, b.W, v.C, b.C, v.coff, out, (hipStream_t)stream), "debug copy");
     return VTI_OK;
 }
@@ -709,7 +716,7 @@ int32_t vti_debug_conv2d(int32_t dtype, const void* dev_in, int32_t B, int32_t H
                          int32_t iters, float* ms_out, int32_t* cfg_out, void* stream) {
     if (!dev_in || !host_w || !host_b || !dev_out || B < 1 || H < 1 || W < 1 || c1 < 1 || c2 < 1 || iters < 1)
         return fail(nullptr, VTI_ERR_ARG, "vti_debug_conv2d: bad argument");
-    if ((dtype != VTI_F16 && dtype != VTI_F32) || (kind < 0 || kind > 2))
+    if ((dtype != VTI_F16 && dtype != VTI_F32 && dtype != VTI_H2) || (kind < 0 || kind > 2))
         return fail(nullptr, VTI_ERR_ARG, "vti_debug_conv2d: bad dtype/kind");
     const bool conv0 = (c1 == 3);   // u8 HWC3 input, the stem conv
     if (conv0 ? !(k == 3 && s == 2 && kind == 0) : (c1 % 16 != 0))
@@ -726,7 +733,8 @@ int32_t vti_debug_conv2d(int32_t dtype, const void* dev_in, int32_t B, int32_t H
     if (cfg_out) { cfg_out[0] = g.TH; cfg_out[1] = g.TW; cfg_out[2] = g.WN; cfg_out[3] = g.NREP; cfg_out[4] = (int32_t)g.lds * (g.pk ? -1 : 1); }   // negative LDS size = persistent kernel
     std::vector<uint8_t> wpk(packed_conv_bytes(r, conv0, g));
     std::vector<float> bias((size_t)g.ntiles_n * 16);
-    pack_conv(dtype, r, conv0, g, host_w, host_b, wpk.data(), bias.data());
+    float alpha = 1.f;
+    pack_conv(dtype, r, conv0, g, host_w, host_b, wpk.data(), bias.data(), 0, &alpha);
     void* d_w = nullptr; float* d_b = nullptr;
     hipStream_t st = (hipStream_t)stream;
     VTI_HIP(nullptr, hipMalloc(&d_w, wpk.size()), "hipMalloc");
@@ -740,6 +748,7 @@ int32_t vti_debug_conv2d(int32_t dtype, const void* dev_in, int32_t B, int32_t H
         ConvParams p;
         fill_conv_params(dtype == VTI_F16 ? 2 : 4, p, r, g, B, dev_in, in_ld, in_coff, dev_out, out_ld, out_coff, dev_res, res_ld, res_coff, d_w, d_b,
                          out_f32 != 0, swap_rb);
+        p.alpha = alpha; p.alpha2 = p.alpha0 = 1.f;
         const int ks = kind == 2 ? 1 : k, ss = kind == 2 ? 1 : s;
 #ifdef VTI_STAMPS
         {   // diagnostic build: one stamped launch, medians of the phase intervals to stderr

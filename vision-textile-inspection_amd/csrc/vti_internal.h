@@ -17,7 +17,7 @@ constexpr int kMaxDevices = 64;
 inline int current_device_slot() { int d = 0; (void)hipGetDevice(&d); return (unsigned)d < (unsigned)kMaxDevices ? d : 0; }
 
 // ---- plan ---------------------------------------------------------------------------
-enum ElemKind { EL_T = 0, EL_F32 = 1, EL_U8 = 2 };   // EL_T = ctx dtype (fp16 or fp32)
+enum ElemKind { EL_T = 0, EL_F32 = 1, EL_U8 = 2 };   // EL_T = ctx dtype (fp16, fp32, or h2 = split-fp16 pairs, 4 bytes)
 
 struct Buf {             // one NHWC activation tensor [max_batch, H, W, C]
     int C, H, W;
@@ -131,6 +131,8 @@ struct ConvParams {
     const void* in2; int in2_ld, in2_coff, up_C; unsigned in2_bytes;
     int fold;                            // convfold_kernel: stage-2 output grid is 2 Hout x 2 Wout, stage-1 bias = p.bias[border class][64]
     const void* w0; const float* bias0;  // stem_l1_kernel: the stem's packed weights / bias (wpk/bias = layer 1, w2/bias2 = the fused 1x1 third conv)
+    // VTI_H2 only: accumulator scales 1 / (SW * 16) of the weights behind wpk / w2 / w0 (weights.cpp: emit_packed); 1 otherwise
+    float alpha, alpha2, alpha0;
     unsigned long long* stamps;          // diagnostic build only (VTI_STAMPS): 16 s_memtime slots per workgroup
 };
 
@@ -144,19 +146,19 @@ bool conv_cfg_fits(int ks, int stride, int mode, int TH, int TW, int WN, int NRE
 hipError_t launch_stem_l1(int dtype, const ConvParams& p, hipStream_t st);
 size_t stem_l1_lds_bytes(int dtype);
 void stem_l1_tile(int* th, int* tw);
-void pack_stem_toeplitz(int dtype, const ConvRow& r0, const float* w, const float* b, uint8_t* dst_w, float* dst_b);
+void pack_stem_toeplitz(int dtype, const ConvRow& r0, const float* w, const float* b, uint8_t* dst_w, float* dst_b, float* alpha = nullptr);
 size_t packed_stem_toeplitz_bytes(int dtype);
 // ConvTranspose2d(C,C,2,2) folded into the following 3x3 conv (+ its fused 1x1): four 2x2 convs on the low-resolution map
 hipError_t launch_convfold(int dtype, const ConvParams& p, size_t lds_bytes, hipStream_t st);
 size_t convfold_lds_bytes(int TH, int TW);
 bool convfold_supported(int c_in, int c_mid, int c_out, int ntiles2);
 void pack_conv_fold(int dtype, const ConvRow& rU, const ConvRow& rV, const ConvCfg& c, const float* wU, const float* bU,
-                    const float* wV, const float* bV, uint8_t* dst_w, float* dst_b);
+                    const float* wV, const float* bV, uint8_t* dst_w, float* dst_b, float* alpha = nullptr);
 size_t packed_fold_bytes(const ConvCfg& c);
 hipError_t launch_conv_pk_fold(int dtype, const ConvParams& p, size_t lds_bytes, hipStream_t st);   // the same on the persistent schedule
 size_t conv_pk_fold_lds_bytes(int nchunks, int depth);
 int conv_pk_fold_depth(int nchunks);
-void pack_conv_l1pairs(int dtype, const ConvRow& r1, const float* w, const float* b, uint8_t* dst_w, float* dst_b);
+void pack_conv_l1pairs(int dtype, const ConvRow& r1, const float* w, const float* b, uint8_t* dst_w, float* dst_b, float* alpha = nullptr);
 size_t packed_l1pairs_bytes(int dtype);
 // conv_pk.hip: persistent 3x3/s1 kernel
 hipError_t launch_conv_pk(int dtype, int nrep, const ConvParams& p, size_t lds_bytes, hipStream_t st);
@@ -236,14 +238,14 @@ void choose_conv_cfg(int dtype, const ConvRow& r, bool conv0, int max_batch, Con
                      int th = 0, int tw = 0, int wn = 0, int nrep = 0, bool allow_pk = true);
 // weights.cpp: one conv's weights -> fragment order; dst_w has cfg.nchunks*ntiles_n*taps KiB, dst_b ntiles_n*16 floats
 void pack_conv(int dtype, const ConvRow& r, bool conv0, const ConvCfg& c, const float* w, const float* b,
-               uint8_t* dst_w, float* dst_b, int cin_off = 0);      // cin_off: the conv's input channels sit at K positions cin_off.. of the chunk
+               uint8_t* dst_w, float* dst_b, int cin_off = 0, float* alpha = nullptr);      // cin_off: the conv's input channels sit at K positions cin_off.. of the chunk; alpha: see ConvParams
 size_t packed_conv_bytes(const ConvRow& r, bool conv0, const ConvCfg& c);
 // fused second stage: the 1x1 conv `r2` packed against the accumulator layout of a producer with nrep1 cout tiles
 void pack_conv_stage2(int dtype, const ConvRow& r2, int nrep1, const float* w, const float* b, uint8_t* dst_w, float* dst_b,
-                      bool natural_rows = false);
+                      bool natural_rows = false, float* alpha = nullptr);
 size_t packed_stage2_bytes(int dtype, const ConvRow& r2, int nrep1);
 // weights.cpp: parse VTIW1 + pack into MFMA fragment order (host memory)
 std::string pack_weights(const Plan& plan, const void* blob, size_t nbytes,
-                         std::vector<uint8_t>& wpk, std::vector<float>& bias);
+                         std::vector<uint8_t>& wpk, std::vector<float>& bias, std::vector<float>& alpha);
 
 }  // namespace vti

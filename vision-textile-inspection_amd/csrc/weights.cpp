@@ -16,6 +16,8 @@
 static inline int perm_cout(int nt, int r, int nrep) {
     return (nt / nrep) * 16 * nrep + (r >> 2) * 4 * nrep + (nt % nrep) * 4 + (r & 3);
 }
+#include <algorithm>
+#include <cmath>
 #include <cstring>
 
 #include "vti_internal.h"
@@ -28,17 +30,41 @@ struct Rec { char name[48]; uint32_t c1, c2, k, s, kind; char pad[12]; };
 static_assert(sizeof(Hdr) == 64 && sizeof(Rec) == 80, "VTIW1 record sizes");
 }  // namespace
 
+// Writes n packed elements in the engine's storage type.  h2 (split-fp16 pairs, conv_dev.h): the values are scaled by SW, the power
+// of two that puts max|v| in [2^13, 2^14) (so that the lo halves of all but vanishing weights are NORMAL fp16 numbers), stored as
+// (hi | lo << 16) with hi = fp16(v SW), lo = fp16(v SW - hi); *alpha = 1 / (SW * 16) is what the kernel multiplies its accumulator
+// by (16 = H2_SX, the activation scale of conv_dev.h).
+static void emit_packed(int dtype, const std::vector<float>& v, uint8_t* dst, float* alpha) {
+    if (dtype == VTI_F16) { for (size_t i = 0; i < v.size(); ++i) ((_Float16*)dst)[i] = (_Float16)v[i]; if (alpha) *alpha = 1.f; return; }
+    if (dtype == VTI_F32) { memcpy(dst, v.data(), v.size() * 4); if (alpha) *alpha = 1.f; return; }
+    float mx = 0.f;
+    for (float x : v) mx = std::max(mx, std::fabs(x));
+    int e = 0;
+    if (mx > 0.f) (void)std::frexp(mx, &e);            // mx = m 2^e, m in [0.5, 1)
+    const float sw = mx > 0.f ? std::ldexp(1.0f, 14 - e) : 1.0f;
+    for (size_t i = 0; i < v.size(); ++i) {
+        const float sv = v[i] * sw;
+        const _Float16 hi = (_Float16)sv;
+        const _Float16 lo = (_Float16)(sv - (float)hi);
+        uint16_t hb, lb;
+        memcpy(&hb, &hi, 2); memcpy(&lb, &lo, 2);
+        ((uint32_t*)dst)[i] = (uint32_t)hb | ((uint32_t)lb << 16);
+    }
+    if (alpha) *alpha = 1.0f / (sw * 16.0f);
+}
+
 size_t packed_conv_bytes(const ConvRow& r, bool conv0, const ConvCfg& c) {
     const int taps = (conv0 || r.kind == 2) ? 1 : r.k * r.k;
     return (size_t)c.nchunks * c.ntiles_n * taps * 64 * 16;
 }
 
 void pack_conv(int dtype, const ConvRow& r, bool conv0, const ConvCfg& c, const float* w, const float* b,
-               uint8_t* dst, float* bd, int cin_off) {
+               uint8_t* dst, float* bd, int cin_off, float* alpha) {
     const bool f16 = dtype == VTI_F16;
     const int KC = f16 ? 32 : 16, VEC = f16 ? 8 : 4;
     const bool deconv = r.kind == 2;
     const int taps = (conv0 || deconv) ? 1 : r.k * r.k;
+    std::vector<float> pv((size_t)c.nchunks * c.ntiles_n * taps * 64 * VEC);
     for (int ck = 0; ck < c.nchunks; ++ck)
         for (int nt = 0; nt < c.ntiles_n; ++nt)
             for (int tap = 0; tap < taps; ++tap)
@@ -63,9 +89,9 @@ void pack_conv(int dtype, const ConvRow& r, bool conv0, const ConvCfg& c, const 
                             }
                         }
                         const size_t e = ((((size_t)ck * c.ntiles_n + nt) * taps + tap) * 64 + lane) * VEC + j;
-                        if (f16) ((_Float16*)dst)[e] = (_Float16)v;
-                        else ((float*)dst)[e] = v;
+                        pv[e] = v;
                     }
+    emit_packed(dtype, pv, dst, alpha);
     for (int n = 0; n < c.ntiles_n * 16; ++n) bd[n] = n < c.gemm_n ? b[deconv ? n % r.c2 : n] : 0.f;
 }
 
@@ -86,10 +112,11 @@ size_t packed_stage2_bytes(int dtype, const ConvRow& r2, int nrep1) {
 // natural_rows: output channel of tile n2, fragment row r is 16*n2 + r (the transposed pred stage, where the
 // weights are the MFMA column operand and a lane's column IS its channel).
 void pack_conv_stage2(int dtype, const ConvRow& r2, int nrep1, const float* w, const float* b, uint8_t* dst, float* bd,
-                      bool natural_rows) {
+                      bool natural_rows, float* alpha) {
     const bool f16 = dtype == VTI_F16;
     const int kt = f16 ? (nrep1 + 1) / 2 : nrep1, VEC = f16 ? 8 : 4;
     const int nt2 = (r2.c2 + 15) / 16;
+    std::vector<float> pv((size_t)kt * nt2 * 64 * VEC);
     for (int t = 0; t < kt; ++t)
         for (int n2 = 0; n2 < nt2; ++n2)
             for (int lane = 0; lane < 64; ++lane)
@@ -99,9 +126,9 @@ void pack_conv_stage2(int dtype, const ConvRow& r2, int nrep1, const float* w, c
                     const int cm = g * 4 * nrep1 + n1 * 4 + (f16 ? (jj & 3) : jj);
                     const float v = (n1 < nrep1 && co < r2.c2 && cm < r2.c1) ? w[(size_t)co * r2.c1 + cm] : 0.f;
                     const size_t e = (((size_t)t * nt2 + n2) * 64 + lane) * VEC + jj;
-                    if (f16) ((_Float16*)dst)[e] = (_Float16)v;
-                    else ((float*)dst)[e] = v;
+                    pv[e] = v;
                 }
+    emit_packed(dtype, pv, dst, alpha);
     for (int n = 0; n < nt2 * 16; ++n) bd[n] = n < r2.c2 ? b[n] : 0.f;
 }
 
@@ -120,7 +147,7 @@ void pack_conv_stage2(int dtype, const ConvRow& r2, int nrep1, const float* w, c
 size_t packed_fold_bytes(const ConvCfg& c) { return (size_t)c.nchunks * c.ntiles_n * 4 * 1024; }
 
 void pack_conv_fold(int dtype, const ConvRow& rU, const ConvRow& rV, const ConvCfg& c, const float* wU, const float* bU,
-                    const float* wV, const float* bV, uint8_t* dst_w, float* dst_b) {
+                    const float* wV, const float* bV, uint8_t* dst_w, float* dst_b, float* alpha) {
     const int C = rU.c1, M = rU.c2, O = rV.c2;
     // tap (dy in -1..1) of output parity py -> (window row a, deconv parity r): source row 2y+py+dy = 2 (y-1+py+a) + r
     auto split = [](int py, int dy, int& a, int& r) {
@@ -159,7 +186,7 @@ void pack_conv_fold(int dtype, const ConvRow& rU, const ConvRow& rV, const ConvC
     ConvCfg sc = c;
     sc.gemm_n = 4 * O;
     std::vector<float> zero_b((size_t)4 * O, 0.f), bias_sink((size_t)c.ntiles_n * 16);
-    pack_conv(dtype, syn, false, sc, weff.data(), zero_b.data(), dst_w, bias_sink.data());
+    pack_conv(dtype, syn, false, sc, weff.data(), zero_b.data(), dst_w, bias_sink.data(), 0, alpha);
     // bias table [cy][cx][O]: class 0 = first row/column (tap -1 outside), 1 = interior, 2 = last (tap +1 outside)
     for (int cy = 0; cy < 3; ++cy)
         for (int cx = 0; cx < 3; ++cx)
@@ -180,9 +207,10 @@ void pack_conv_fold(int dtype, const ConvRow& rU, const ConvRow& rV, const ConvC
 // zero elsewhere.  Layout [swap 0..1][p][kh][chunk][lane][VEC]; natural row order (one n-tile: 16 stem channels).
 size_t packed_stem_toeplitz_bytes(int dtype) { return (size_t)2 * 4 * 3 * (dtype == VTI_F16 ? 1 : 2) * 1024; }
 
-void pack_stem_toeplitz(int dtype, const ConvRow& r0, const float* w, const float* b, uint8_t* dst, float* bd) {
+void pack_stem_toeplitz(int dtype, const ConvRow& r0, const float* w, const float* b, uint8_t* dst, float* bd, float* alpha) {
     const bool f16 = dtype == VTI_F16;
     const int KC = f16 ? 32 : 16, VEC = f16 ? 8 : 4, NCH = 32 / KC;
+    std::vector<float> pv((size_t)2 * 4 * 3 * NCH * 64 * VEC);
     for (int sw = 0; sw < 2; ++sw)
         for (int pp = 0; pp < 4; ++pp)
             for (int kh = 0; kh < 3; ++kh)
@@ -197,9 +225,9 @@ void pack_stem_toeplitz(int dtype, const ConvRow& r0, const float* w, const floa
                                 v = w[(((size_t)co * 3 + chn) * 3 + kh) * 3 + kw];
                             }
                             const size_t e = ((((((size_t)sw * 4 + pp) * 3 + kh) * NCH + c) * 64) + lane) * VEC + j;
-                            if (f16) ((_Float16*)dst)[e] = (_Float16)v;
-                            else ((float*)dst)[e] = v;
+                            pv[e] = v;
                         }
+    emit_packed(dtype, pv, dst, alpha);
     for (int n = 0; n < 16; ++n) bd[n] = n < r0.c2 ? b[n] : 0.f;
 }
 
@@ -208,9 +236,10 @@ void pack_stem_toeplitz(int dtype, const ConvRow& r0, const float* w, const floa
 // fp32: step s = tap s, channels 4 g + j (j < 4).  Layout [step][ntile 0..1][lane][VEC]; rows permuted as for NREP = 2.
 size_t packed_l1pairs_bytes(int dtype) { return (size_t)(dtype == VTI_F16 ? 5 : 9) * 2 * 1024; }
 
-void pack_conv_l1pairs(int dtype, const ConvRow& r1, const float* w, const float* b, uint8_t* dst, float* bd) {
+void pack_conv_l1pairs(int dtype, const ConvRow& r1, const float* w, const float* b, uint8_t* dst, float* bd, float* alpha) {
     const bool f16 = dtype == VTI_F16;
     const int NS = f16 ? 5 : 9, VEC = f16 ? 8 : 4;
+    std::vector<float> pv((size_t)NS * 2 * 64 * VEC);
     for (int s = 0; s < NS; ++s)
         for (int nt = 0; nt < 2; ++nt)
             for (int lane = 0; lane < 64; ++lane)
@@ -220,14 +249,14 @@ void pack_conv_l1pairs(int dtype, const ConvRow& r1, const float* w, const float
                     const int ch = f16 ? (g & 1) * 8 + j : g * 4 + j;
                     const float v = (tap < 9 && co < r1.c2) ? w[((size_t)co * r1.c1 + ch) * 9 + tap] : 0.f;
                     const size_t e = (((size_t)s * 2 + nt) * 64 + lane) * VEC + j;
-                    if (f16) ((_Float16*)dst)[e] = (_Float16)v;
-                    else ((float*)dst)[e] = v;
+                    pv[e] = v;
                 }
+    emit_packed(dtype, pv, dst, alpha);
     for (int n = 0; n < 32; ++n) bd[n] = n < r1.c2 ? b[n] : 0.f;
 }
 
 std::string pack_weights(const Plan& plan, const void* blob, size_t nbytes, std::vector<uint8_t>& wpk,
-                         std::vector<float>& bias) {
+                         std::vector<float>& bias, std::vector<float>& alpha) {
     const uint8_t* p = (const uint8_t*)blob;
     if (!blob || nbytes < sizeof(Hdr)) return "weights: container too small";
     Hdr h;
@@ -240,6 +269,7 @@ std::string pack_weights(const Plan& plan, const void* blob, size_t nbytes, std:
 
     wpk.assign(plan.wpk_bytes, 0);
     bias.assign(plan.bias_floats, 0.f);
+    alpha.assign(plan.convs.size(), 1.f);       // per conv: accumulator scale of its packed weights (1 unless dtype == VTI_H2)
 
     // conv index -> op (cfg); a conv fused into its producer's epilogue maps to that producer
     std::vector<const Op*> op_of(plan.convs.size(), nullptr), host_of(plan.convs.size(), nullptr), l1_host(plan.convs.size(), nullptr);
@@ -299,28 +329,28 @@ std::string pack_weights(const Plan& plan, const void* blob, size_t nbytes, std:
         }
         if (pair_host[i]) {
             const ConvCfg& hc = pair_host[i]->cfg;
-            pack_conv(plan.desc.dtype, r, false, hc, w.data(), b.data(), wpk.data() + hc.wpk_off2, bias.data() + hc.bias_off2);
+            pack_conv(plan.desc.dtype, r, false, hc, w.data(), b.data(), wpk.data() + hc.wpk_off2, bias.data() + hc.bias_off2, 0, &alpha[i]);
             continue;
         }
         if (fold_host[i]) { fold_w = w; fold_b = b; continue; }          // packed together with the 3x3 that follows
         if (op_of[i] && op_of[i]->fold >= 0) {
             const Op& op = *op_of[i];
             pack_conv_fold(plan.desc.dtype, plan.convs[op.fold], r, op.cfg, fold_w.data(), fold_b.data(), w.data(), b.data(),
-                           wpk.data() + op.cfg.wpk_off, bias.data() + op.cfg.bias_off);
+                           wpk.data() + op.cfg.wpk_off, bias.data() + op.cfg.bias_off, &alpha[i]);
             continue;
         }
         if (l1_host[i]) {      // layer 1 computed inside the stem's kernel
             const ConvCfg& hc = l1_host[i]->cfg;
-            pack_conv_l1pairs(plan.desc.dtype, r, w.data(), b.data(), wpk.data() + hc.wpk_off2, bias.data() + hc.bias_off2);
+            pack_conv_l1pairs(plan.desc.dtype, r, w.data(), b.data(), wpk.data() + hc.wpk_off2, bias.data() + hc.bias_off2, &alpha[i]);
             continue;
         }
         if (host_of[i]) {
             const ConvCfg& hc = host_of[i]->cfg;
             if (host_of[i]->fused_l1 >= 0)      // third conv of the stem kernel: K order of layer 1's two n-tiles
-                pack_conv_stage2(plan.desc.dtype, r, 2, w.data(), b.data(), wpk.data() + hc.wpk_off3, bias.data() + hc.bias_off3, false);
+                pack_conv_stage2(plan.desc.dtype, r, 2, w.data(), b.data(), wpk.data() + hc.wpk_off3, bias.data() + hc.bias_off3, false, &alpha[i]);
             else
                 pack_conv_stage2(plan.desc.dtype, r, hc.NREP, w.data(), b.data(), wpk.data() + hc.wpk_off2, bias.data() + hc.bias_off2,
-                                 host_of[i]->nat2 != 0);
+                                 host_of[i]->nat2 != 0, &alpha[i]);
             continue;
         }
         const Op& op = *op_of[i];
@@ -329,11 +359,11 @@ std::string pack_weights(const Plan& plan, const void* blob, size_t nbytes, std:
             continue;
         }
         if (op.kind == OP_CONV0 && op.fused_l1 >= 0) {       // the stem inside stem_l1_kernel: banded (Toeplitz) fragments
-            pack_stem_toeplitz(plan.desc.dtype, r, w.data(), b.data(), wpk.data() + op.cfg.wpk_off, bias.data() + op.cfg.bias_off);
+            pack_stem_toeplitz(plan.desc.dtype, r, w.data(), b.data(), wpk.data() + op.cfg.wpk_off, bias.data() + op.cfg.bias_off, &alpha[i]);
             continue;
         }
         pack_conv(plan.desc.dtype, r, op.kind == OP_CONV0, op.cfg, w.data(), b.data(), wpk.data() + op.cfg.wpk_off,
-                  bias.data() + op.cfg.bias_off);
+                  bias.data() + op.cfg.bias_off, 0, &alpha[i]);
     }
     if (off != nbytes) return "weights: trailing bytes in container";
     return "";
