@@ -57,7 +57,8 @@ def calibrated_weights(vti_amd, eng, frames, conf, target):
     pred, _ = eng.forward(frames[:8].contiguous())
     p = pred[:, 4:4 + eng.nc].amax(1).flatten().clamp(1e-7, 1 - 1e-7)
     logit = torch.log(p / (1 - p))
-    kth = torch.topk(logit, target * 8).values[-1].item()
+    top = torch.topk(logit, target * 8 + 1).values
+    kth = 0.5 * (top[-2].item() + top[-1].item())       # midway between two anchors: no score sits exactly on the threshold
     bias = float(math.log(conf / (1 - conf)) - kth)
     blob = vti_amd.random_weights(eng, seed=1, cls_bias=bias)
     eng.load_weights(blob, torch.cuda.current_device())

@@ -35,7 +35,8 @@ def _calibrated_model(vti_amd, nc, dtype, frame, imgsz, conf, target=400):
     pred, _ = eng.forward(inp)
     p = pred[0, 4:4 + nc].amax(0).clamp(1e-6, 1 - 1e-6)
     logit = torch.log(p / (1 - p))
-    kth = torch.topk(logit, target).values[-1].item()
+    top = torch.topk(logit, target + 1).values
+    kth = 0.5 * (top[-2].item() + top[-1].item())      # between two anchors, so that none sits exactly ON the threshold
     bias = float(np.log(conf / (1 - conf)) - kth)
     return vti_amd.YOLO(None, scale="n", nc=nc, seed=1, cls_bias=bias, dtype=dtype, max_batch=2)
 
