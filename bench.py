@@ -2,7 +2,14 @@
 """Headline benchmark: frames/s of the YOLOv8n-seg hot path (BASELINE.json metric).
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    N > 1 works both ways: under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...`
+    (RANK / LOCAL_RANK / WORLD_SIZE from the environment), and as the plain command above -- the parent then starts N fresh
+    rank processes itself (before it touches a GPU; never exec), relays rank 0's JSON line and returns the worst exit code.
+    `--backend gloo --dry` runs the launch + per-step exchange + JSON path on CPU tensors without any kernel (CPU tests).
+
+The headline dtype is h2 (split-fp16 pairs on the fp16 matrix pipe, include/vti.h): the dtype whose detections and masks meet the
+north-star tolerance against the fp32 CPU oracle (`parity.meets_north_star`).  The plain-fp16 engine (faster, but its results
+drift past the tolerance) and the exact-f32 engine are reported beside it as `fp16_engine` / `fp32_engine`.
 
 One step = one pass of the whole predict pipeline (letterbox[identity] -> 76-conv network -> decode ->
 NMS -> mask assembly (bit-packed) -> scale_boxes) over one batch of 64 synthetic 640x640x3 uint8
@@ -17,10 +24,11 @@ Before the W warm-up steps the chip is pre-heated with >= --preheat seconds of t
 MFMA load; a 20-step run is only ~50 ms long), so the timed steps land on settled clocks.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with these extra objects:
-  parity       -- the benchmarked engine (fp16) against the fp32 CPU oracle on a few of the bench frames, AFTER the timed
-                  region: mask IoU, |d box| in px and normalised, kept-set equality (north_star: IoU >= 0.999, |d box| < 1e-3).
-  fp32_engine  -- the same pipeline on the exact-f32 MFMA engine (the dtype that meets the north-star tolerance): its own
-                  frames/s, roofline fraction against the f32 matrix peak, and its parity object.
+  parity       -- the benchmarked engine against the fp32 CPU oracle on --parity-frames of the bench frames, AFTER the timed
+                  region, through the same entry points the timed loop uses: mask IoU (min / p1 / mean), |d box| in px and
+                  normalised, kept-set equality (north_star: IoU >= 0.999, |d box| < 1e-3, same kept set).
+  fp16_engine / fp32_engine -- the same pipeline, weights and frames on the other two storage types, each with the driver's
+                  --steps / --warmup, its own roofline fraction and parity object.
   roofline     -- the conv network (76 MFMA conv launches, >85 % of the step) against the dense fp16
                   MFMA peak: achieved = 2*MAC of all convs per forward / forward time measured with HIP
                   events on the launch stream inside the timed region.
@@ -31,6 +39,8 @@ import argparse
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -134,10 +144,10 @@ def parity_check(eng, blob, frames_dev, nc, H, W, n_frames):
     return res
 
 
-def fp32_engine_line(vti_amd, blob, frames, B, H, W, nc, cap, dev, n_par, steps=5, warmup=2):
-    """The same pipeline on the exact-f32 MFMA engine (the dtype whose results meet the north-star tolerance): frames/s,
-    its own roofline fraction (against the f32 matrix peak) and its parity against the fp32 CPU oracle."""
-    eng = vti_amd.Engine("n", nc, H=H, W=W, max_batch=B, dtype="fp32")
+def other_engine_line(vti_amd, dtype, blob, frames, B, H, W, nc, cap, dev, n_par, steps, warmup):
+    """The same pipeline, weights and frames on another storage type: frames/s, its own roofline fraction and its parity against
+    the fp32 CPU oracle.  Timed like the headline: >= 0.5 s of untimed steps, `warmup` steps, then `steps` steps between syncs."""
+    eng = vti_amd.Engine("n", nc, H=H, W=W, max_batch=B, dtype=dtype)
     eng.load_weights(blob, torch.cuda.current_device())
     o = eng.alloc_outputs(B, MAX_DET, cap, "bits", dev)
     st = torch.cuda.current_stream()
@@ -150,6 +160,11 @@ def fp32_engine_line(vti_amd, blob, frames, B, H, W, nc, cap, dev, n_par, steps=
         eng.nms(o["pred"], CONF, IOU, MAX_DET, False, dets=o["dets"], counts=o["counts"], best=None if UNSCORED else o["best"])
         eng.masks(o["dets"], o["counts"], o["proto"], "logit", "bits", capacity=cap, masks=o["masks"], offsets=o["offsets"])
         eng.scale_boxes(o["dets"], o["counts"], H, W, xyxy=o["xyxy"])
+    t_heat = time.perf_counter()
+    while time.perf_counter() - t_heat < 0.5:
+        for _ in range(4):
+            step()
+        torch.cuda.synchronize()
     for _ in range(warmup):
         step()
     torch.cuda.synchronize()
@@ -160,13 +175,109 @@ def fp32_engine_line(vti_amd, blob, frames, B, H, W, nc, cap, dev, n_par, steps=
     dt = time.perf_counter() - t0
     fwd_ms = float(np.mean([ev[2 * i].elapsed_time(ev[2 * i + 1]) for i in range(steps)]))
     ach = 2.0 * eng.macs_per_frame * B / (fwd_ms * 1e-3) / 1e12
-    res = dict(dtype="f32", value=round(B * steps / dt, 1), unit="frames/s", steps=steps, warmup=warmup, ms_per_step=round(dt / steps * 1e3, 4),
-               roofline=dict(bound="mfma", achieved=round(ach, 2), peak=F32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
-                             frac=round(ach / F32_MFMA_PEAK_TFLOPS, 5), avg_ms=round(fwd_ms, 4)),
-               note="same weights, frames and pipeline as the headline line, exact-f32 MFMA (v_mfma_f32_16x16x4_f32), fp32 activations")
+    peak = F32_MFMA_PEAK_TFLOPS if dtype == "fp32" else MFMA_PEAK_TFLOPS
+    res = dict(dtype=DTYPE_TAG[dtype], value=round(B * steps / dt, 1), unit="frames/s", steps=steps, warmup=warmup, ms_per_step=round(dt / steps * 1e3, 4),
+               roofline=dict(bound="mfma", achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 5), avg_ms=round(fwd_ms, 4)),
+               note=DTYPE_NOTE[dtype])
     if n_par > 0:
         res["parity"] = parity_check(eng, blob, frames, nc, H, W, n_par)
     return res
+
+
+DTYPE_TAG = {"h2": "f16x2", "fp16": "f16", "fp32": "f32"}
+DTYPE_NOTE = {
+    "h2": "split-fp16 storage: every weight and activation an fp16 (hi, lo) pair (22-23 significant bits), all products on the fp16 matrix "
+          "pipe (v_mfma_f32_16x16x32_f16, two per 16 input channels), f32 accumulation",
+    "fp16": "plain fp16 storage of weights and activations, one v_mfma_f32_16x16x32_f16 per 32 input channels: fastest, but 11-bit storage "
+            "drifts past the north-star tolerance on these networks (profiles/r03_precision_ablation.txt: >= 20 bits needed)",
+    "fp32": "exact-f32 MFMA (v_mfma_f32_16x16x4_f32), fp32 activations",
+}
+
+
+def free_port():
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (this parent has touched no GPU and never
+    execs), let rank 0's JSON line through on stdout, return the worst exit code.  A rank that dies takes the others down."""
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    worst, deadline = 0, None
+    while any(p.poll() is None for p in procs):
+        for p in procs:
+            rc = p.poll()
+            if rc not in (None, 0) and deadline is None:
+                worst, deadline = rc, time.time() + 20.0       # the others are probably stuck in a collective: give them 20 s
+        if deadline is not None and time.time() > deadline:
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            deadline = time.time() + 1e9
+        time.sleep(0.2)
+    for p in procs:
+        if p.returncode != 0 and worst == 0:
+            worst = p.returncode
+    return worst if worst >= 0 else 128 - worst
+
+
+def dry_main(args, world, rank):
+    """--dry: the launch, the per-step exchange (scatter of frames / gather of detections [+ live masks]) and the JSON line on CPU
+    tensors over gloo -- no GPU, no kernel; the "compute" of a step writes rank-tagged outputs.  For the CPU test of the N > 1 path."""
+    import torch.distributed as dist
+    from vti_amd import dataparallel as dp
+    dev = torch.device("cpu")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(args.backend, rank=rank, world_size=world)
+    B, H, W, nm, cap = args.batch, 32, 32, 32, args.batch * 4
+    outs = [dict(dets=torch.zeros((B, MAX_DET, 6 + nm)), counts=torch.zeros((B,), dtype=torch.int32), xyxy=torch.zeros((B, MAX_DET, 4)),
+                 offsets=torch.zeros((B + 1,), dtype=torch.int32), masks=torch.zeros((cap, H, W // 8), dtype=torch.uint8),
+                 stats=torch.zeros((cap, 5), dtype=torch.int64), envelope=torch.zeros((B, W), dtype=torch.int32)) for _ in range(2)]
+    root_pool = torch.arange(world * B * H * W * 3, dtype=torch.int64).remainder(251).to(torch.uint8).view(world * B, H, W, 3) if rank == 0 else None
+    shards = [torch.zeros((B, H, W, 3), dtype=torch.uint8) for _ in range(2)]
+    ok, gathered = True, None
+    exchange = world > 1 and not args.no_exchange
+
+    def step(k):
+        nonlocal ok, gathered
+        cur, nxt = k & 1, (k + 1) & 1
+        if exchange:
+            shards[nxt] = dp.scatter_frames(root_pool, B, (H, W, 3), dev)
+            gathered = dp.gather_detections(outs[nxt], reuse=nxt)
+            if args.gather_masks:
+                dp.gather_live_masks(outs[nxt]["masks"], outs[nxt]["offsets"])
+        o = outs[cur]
+        o["counts"].fill_(1 + rank); o["dets"].fill_(float(rank)); o["offsets"].copy_(torch.arange(B + 1, dtype=torch.int32) * (1 + rank))
+    t0 = time.perf_counter()
+    for k in range(args.warmup + args.steps):
+        step(k)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if exchange:
+        lo = rank * B
+        ok &= bool(torch.equal(shards[(args.warmup + args.steps) & 1], torch.arange(world * B * H * W * 3, dtype=torch.int64).remainder(251).to(torch.uint8).view(world * B, H, W, 3)[lo:lo + B]))
+        if rank == 0:
+            ok &= gathered is not None and gathered["counts"].shape[0] == world * B and gathered["counts"].view(world, B)[:, 0].tolist() == [1 + r for r in range(world)]
+        flag = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        ok = bool(flag.item() == 1.0)
+    if rank == 0:
+        print(json.dumps({"metric": "frames/sec whole-node, YOLOv8n-seg 640x640 bs=64; mask IoU vs CPU ref", "dry": True, "value": round(world * B * args.steps / elapsed, 1),
+                          "unit": "frames/s (no kernels: launch + exchange only)", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ranks": dist.get_world_size() if world > 1 else 1, "backend": args.backend, "exchange_ok": ok,
+                          "exchange": "scatter of uint8 frames + gather of dets/counts/xyxy/offsets/stats/envelope" + ("; + live masks" if args.gather_masks else "") if exchange else "none",
+                          "config": {"workload": "dry run: CPU tensors, no kernels", "global_batch": world * B, "parallelism": f"dp{world}"}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    return 0 if ok else 3
 
 
 def main():
@@ -175,31 +286,40 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step")
-    ap.add_argument("--dtype", default="fp16", choices=["fp16", "fp32"])
+    ap.add_argument("--dtype", default="h2", choices=["h2", "fp16", "fp32"],
+                    help="storage type of the HEADLINE engine (default h2: the one that meets the north-star tolerance)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend for N > 1 (nccl = RCCL; gloo with --dry)")
+    ap.add_argument("--dry", action="store_true", help="no GPU, no kernels: run the rank launch + per-step exchange + JSON path on CPU tensors (tests)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exchange", action="store_true", help="N>1: skip the per-step scatter/gather")
     ap.add_argument("--gather-masks", action="store_true",
                     help="N>1: also ship every rank's LIVE bit-packed mask slots to the root each step (variable-length point-to-point "
                          "gather, one host read of the slot count per step); default: dets/counts/xyxy + on-device reductions only")
     ap.add_argument("--preheat", type=float, default=1.0, help="seconds of untimed steps before the warm-up steps (clock settling)")
-    ap.add_argument("--parity-frames", type=int, default=2, help="bench frames checked against the fp32 CPU oracle after the timed region (0: skip)")
+    ap.add_argument("--parity-frames", type=int, default=8, help="bench frames checked against the fp32 CPU oracle after the timed region (0: skip)")
     ap.add_argument("--no-fp32-line", action="store_true", help="skip the secondary fp32-engine measurement + parity")
+    ap.add_argument("--no-fp16-line", action="store_true", help="skip the secondary plain-fp16-engine measurement + parity")
     ap.add_argument("--pipeline", action="store_true",
                     help="overlap post-processing of batch k-1 with the network of batch k on a second stream: ~6 %% more frames/s "
                          "(24.7k vs 23.2k on one MI355X), but the forward then shares the chip and its in-region HIP-event time (the "
                          "roofline line) is inflated; default: the stages in series on one stream")
     args = ap.parse_args()
 
-    import vti_amd
-    from vti_amd import dataparallel as dp
-
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:      # plain `python bench.py --gpus N`: be the launcher (no GPU touched yet)
+        sys.exit(launch_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
         sys.exit(2)
+    if args.dry:
+        sys.exit(dry_main(args, world, rank))
+
+    import vti_amd
+    from vti_amd import dataparallel as dp
+
     if not torch.cuda.is_available():
         print("bench.py needs a ROCm GPU (no CPU fallback for the product path)", file=sys.stderr)
         sys.exit(2)
@@ -208,7 +328,7 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # "nccl" == RCCL on ROCm
+        dist.init_process_group(args.backend, rank=rank, world_size=world, device_id=dev)   # "nccl" == RCCL on ROCm
 
     B, H, W, nc = args.batch, 640, 640, 80
     eng = vti_amd.Engine("n", nc, H=H, W=W, max_batch=B, dtype=args.dtype)
@@ -218,6 +338,8 @@ def main():
     blob, bias = calibrated_weights(vti_amd, eng, frames, CONF, target=60)
     cap = B * SLOTS_PER_FRAME
     outs = [eng.alloc_outputs(B, MAX_DET, cap, "bits", dev) for _ in range(2)]
+    for o in outs:                           # a gather that runs before this buffer's first post-processing must see "no detections"
+        o["counts"].zero_(); o["offsets"].zero_()
     shards = [frames, frames.clone()]
     FABRIC_CLS = 1                          # the reference's FABRIC_CLASS_ID (config.py:70): whose union envelope the consumer reads
 
@@ -255,7 +377,7 @@ def main():
                 else:
                     comm.wait_stream(main_stream)
                 shards[nxt] = dp.scatter_frames(root_pool, B, (H, W, 3), dev)
-                dp.gather_detections(outs[nxt])
+                dp.gather_detections(outs[nxt], reuse=nxt)
                 if args.gather_masks:
                     dp.gather_live_masks(outs[nxt]["masks"], outs[nxt]["offsets"])
                 ready = torch.cuda.Event()
@@ -348,13 +470,13 @@ def main():
     value = total_frames / elapsed
     flops_per_forward = 2.0 * eng.macs_per_frame * B
     achieved = flops_per_forward / (fwd_ms * 1e-3) / 1e12
-    peak = MFMA_PEAK_TFLOPS if args.dtype == "fp16" else F32_MFMA_PEAK_TFLOPS
+    peak = F32_MFMA_PEAK_TFLOPS if args.dtype == "fp32" else MFMA_PEAK_TFLOPS       # h2 and fp16 both run on the fp16 matrix pipe
 
     # HBM bytes per forward from the committed rocprofv3 PMC passes (tools/make_profiles.sh): only
     # valid for the configuration they were collected on.
     traffic = None
     tpath = next((q for q in (os.path.join(ROOT, "profiles", f"r{r:02d}_hbm_traffic.json") for r in range(9, 0, -1)) if os.path.exists(q)), "")
-    if tpath and B == 64 and args.dtype == "fp16":
+    if tpath and B == 64 and json.load(open(tpath)).get("dtype", "fp16") == args.dtype:
         fam = json.load(open(tpath))["families"]
         traffic = sum(v["total_bytes"] for k, v in fam.items() if k.startswith("conv family") or k in ("decode_kernel", "sppf_pool", "upsample2x"))    # the forward's kernels
 
@@ -363,16 +485,19 @@ def main():
             "metric": "frames/sec whole-node, YOLOv8n-seg 640x640 bs=64; mask IoU vs CPU ref",
             "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f16" if args.dtype == "fp16" else "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": DTYPE_TAG[args.dtype], "dtype_note": DTYPE_NOTE[args.dtype], "data": "synthetic",
             "config": {"workload": f"YOLOv8n-seg nc=80 640x640 bs={B} per GPU, full predict: net + decode + NMS + "
                                    f"bit-packed masks + scale_boxes (BASELINE configs[2]; configs[1] is the bs=1 case)",
                        "global_batch": world * B, "weights": f"seeded random (He, seed 1), class bias calibrated to {bias:.3f}",
                        "conf": CONF, "iou": IOU, "max_det": MAX_DET, "detections_per_frame": round(dets_per_frame, 2),
                        "pipeline": ("post-processing of batch k overlaps the network of batch k+1 on a second stream"
                                     if pipelined else "network and post-processing in series"),
-                       "mask_capacity": cap, "masks_dropped": max(0, int(outs[(args.steps - 1) & 1]["offsets"][-1].item()) - cap), "parallelism": f"dp{world}", "exchange": exch_note},
+                       "mask_capacity": cap, "masks_dropped": max(0, int(outs[(args.steps - 1) & 1]["offsets"][-1].item()) - cap), "parallelism": f"dp{world}", "exchange": exch_note,
+                       "ranks": world, "backend": args.backend if world > 1 else None},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 5), "traffic": traffic,
+                         "mfma_issue_frac": round(achieved / peak * (4.0 if args.dtype == "h2" else 1.0), 5),
+                         "mfma_issue_note": "share of the matrix pipe's time the issued MFMAs occupy: h2 issues 4 fp16 MFMA MACs per algorithmic MAC (hi/lo x hi/lo; `achieved` and `frac` count ALGORITHMIC flops only)",
                          "traffic_note": "HBM bytes per forward (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes, profiles/" + os.path.basename(tpath) + "); algorithmic unfused activation bytes = 91.6 MB/frame",
                          "kernel": f"vti conv family: conv3_pk / conv1_pk (persistent LDS-DMA 3x3 / 1x1) + conv_kernel (fused towers, stride 2) + stem_l1_kernel ({eng.num_launches} launches per forward incl. the SPPF pool; {len(eng.conv_table())} convs, {sum(1 for t in eng.conv_table() if t['fused'])} fused into their producer's kernel, decode fused into the box towers)",
                          "flop_per_launch": flops_per_forward, "avg_ms": round(fwd_ms, 4),
@@ -385,10 +510,10 @@ def main():
         if args.parity_frames > 0:
             line["parity"] = parity_check(eng, blob, frames, nc, H, W, min(args.parity_frames, B))
             line["parity"]["engine"] = line["dtype"]
-            line["parity"]["tolerance"] = ("north_star gate: mask IoU >= 0.999 and |d box| < 1e-3 (normalised by 640) with the same kept set; "
-                                           "see meets_north_star -- the fp16 engine is reported as measured, the fp32 engine line beside it meets the gate")
-        if world == 1 and args.dtype == "fp16" and not args.no_fp32_line:
-            line["fp32_engine"] = fp32_engine_line(vti_amd, blob, frames, B, H, W, nc, cap, dev, min(args.parity_frames, B))
+            line["parity"]["tolerance"] = "north_star gate: mask IoU >= 0.999 for every instance and |d box| < 1e-3 (normalised by 640) with the same kept set and order: see meets_north_star"
+        for other, skip in (("fp16", args.no_fp16_line), ("fp32", args.no_fp32_line)):
+            if world == 1 and other != args.dtype and not skip:
+                line[other + "_engine"] = other_engine_line(vti_amd, other, blob, frames, B, H, W, nc, cap, dev, min(args.parity_frames, B), args.steps, args.warmup)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(blob, H, W, nc)
         print(json.dumps(line), flush=True)

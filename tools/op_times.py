@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 d = sys.argv[1]
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 dtype = sys.argv[3] if len(sys.argv) > 3 else "fp16"
-PEAK_TF = 2517.0 if dtype == "fp16" else 157.3
+PEAK_TF = 157.3 if dtype == "fp32" else 2517.0      # h2 runs on the fp16 matrix pipe (4 MFMAs where fp16 needs one)
 es = 2 if dtype == "fp16" else 4
 import vti_amd
 eng = vti_amd.Engine("n", 80, H=640, W=640, max_batch=B, dtype=dtype)

@@ -32,29 +32,44 @@ def scatter_frames(frames, per_rank, shape_tail, device, src=0, group=None):
     return out
 
 
-def gather_tensor(t, dst=0, group=None):
-    """Gather equally-shaped tensors to `dst`; returns the concatenation there, None elsewhere."""
+_recv = {}      # (key, shape, dtype, device, world) -> the root's receive buffer [world * n, ...], allocated once
+
+
+def gather_tensor(t, dst=0, group=None, key=None):
+    """Gather equally-shaped tensors to `dst`; returns the concatenation there ([world * n, ...]), None elsewhere.
+    With `key` the root receives into a buffer that is allocated once per (key, shape) and reused by every later call (the
+    per-step gathers of bench.py: no allocation and no concatenation copy on the root; the result is overwritten by the next
+    call with the same key)."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
+    t = t.contiguous()
     if rank == dst:
-        parts = [torch.empty_like(t) for _ in range(world)]
-        dist.gather(t.contiguous(), parts, dst=dst, group=group)
-        return torch.cat(parts, 0)
-    dist.gather(t.contiguous(), None, dst=dst, group=group)
+        if key is None:
+            buf = torch.empty((world * t.shape[0], *t.shape[1:]), dtype=t.dtype, device=t.device)
+        else:
+            k = (key, tuple(t.shape), t.dtype, t.device, world)
+            buf = _recv.get(k)
+            if buf is None:
+                buf = _recv[k] = torch.empty((world * t.shape[0], *t.shape[1:]), dtype=t.dtype, device=t.device)
+        parts = list(buf.chunk(world, 0)) if t.shape[0] else [torch.empty_like(t) for _ in range(world)]   # views: the gather lands in place
+        dist.gather(t, parts, dst=dst, group=group)
+        return buf
+    dist.gather(t, None, dst=dst, group=group)
     return None
 
 
 COMPACT_KEYS = ("dets", "counts", "xyxy", "offsets", "stats", "envelope")
 
 
-def gather_detections(out, dst=0, group=None, keys=None):
+def gather_detections(out, dst=0, group=None, keys=None, reuse=None):
     """Gather what the consumer needs from one predict_into() output set: dets f32 [b,max_det,6+nm], counts i32 [b], xyxy f32
     [b,max_det,4], offsets i32 [b+1] and -- when the caller computed them (Engine.mask_stats_bits / envelope_bits: SURVEY 8
     row N1) -- stats i64 [capacity,5] and envelope i32 [b,W0]: a few MB per rank instead of the mask buffer (capacity x H x W/8
     bytes: 210 MB per rank at 64 frames of 640x640, most of it dead slots).  Root gets a dict of concatenated tensors, others
     None.  Masks themselves travel through gather_live_masks when a consumer really wants the bitmaps."""
     keys = [k for k in (keys or COMPACT_KEYS) if k in out and out[k] is not None]
-    got = {k: gather_tensor(out[k], dst, group) for k in keys}
+    # reuse = a caller-chosen tag (e.g. the double-buffer slot): receive buffers are then kept per (tag, key) instead of allocated per call
+    got = {k: gather_tensor(out[k], dst, group, key=None if reuse is None else (reuse, k)) for k in keys}
     return got if dist.get_rank(group) == dst else None
 
 
@@ -65,7 +80,7 @@ def gather_live_masks(masks, offsets, dst=0, group=None):
     live i64 [world]) with rank r's slots at [live[:r].sum(), live[:r+1].sum()); others None."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    n_live = offsets[-1:].to(torch.int64).clamp(max=masks.shape[0])
+    n_live = offsets[-1:].to(torch.int64).clamp(min=0, max=masks.shape[0])     # never trust an uninitialised offsets buffer
     sizes = [torch.zeros_like(n_live) for _ in range(world)]
     dist.all_gather(sizes, n_live, group=group)
     live = torch.cat(sizes).cpu()
