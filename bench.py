@@ -76,8 +76,8 @@ def calibrated_weights(vti_amd, eng, frames, conf, target):
 
 
 def cpu_baseline(blob, H, W, nc, budget_s=12.0):
-    """The oracle's full pipeline (fp32) on the host cores.  `value` is the bs=8 rate (about budget_s of CPU work);
-    `by_batch` adds bs=1 and bs=64, `stage_ms_per_frame` the split at bs=8."""
+    """The oracle's full pipeline (fp32) on the host cores.  `value` is the best of the bs = 1 / 8 / 64 rates (`by_batch`,
+    BASELINE.md section 3; bs=8 gets about budget_s of CPU work), `stage_ms_per_frame` the split at bs=8."""
     from oracle.model import OracleModel
     from oracle.postproc import non_max_suppression, process_mask, scale_boxes
     # host threads: the cores this process may actually use (a 1-GPU box grants 16 of the host's
@@ -123,9 +123,10 @@ def cpu_baseline(blob, H, W, nc, budget_s=12.0):
     split = {k: round(v / (8 * it8) * 1e3, 3) for k, v in stage.items()}
     v1, it1, dt1 = rate(1, 3.0, 16)
     v64, it64, dt64 = rate(64, 4.0, 2)
-    return dict(value=round(v8, 3), unit="frames/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"{it8} iterations of bs=8 {H}x{W} frames, full predict pipeline "
-                       f"(net fp32 + NMS + process_mask), torch-CPU oracle, {dt8:.1f} s",
+    best_bs, best_v = max((("1", v1), ("8", v8), ("64", v64)), key=lambda t: t[1])
+    return dict(value=round(best_v, 3), unit="frames/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"best of three batch sizes (bs={best_bs}); bs=8: {it8} iterations of {H}x{W} frames, full predict pipeline "
+                       f"(net fp32 + NMS + process_mask), torch-CPU oracle, {dt8:.1f} s; bs=1 and bs=64 below",
                 by_batch={"1": round(v1, 3), "8": round(v8, 3), "64": round(v64, 3)},
                 by_batch_sample=f"bs=1: {it1} it / {dt1:.1f} s; bs=64: {it64} it / {dt64:.1f} s",
                 stage_ms_per_frame=split)
@@ -182,6 +183,40 @@ def other_engine_line(vti_amd, dtype, blob, frames, B, H, W, nc, cap, dev, n_par
     if n_par > 0:
         res["parity"] = parity_check(eng, blob, frames, nc, H, W, n_par)
     return res
+
+
+def host_fed_line(vti_amd, eng, frames, B, H, W, cap, dev, steps, warmup):
+    """The same step with the frames starting in HOST memory (main.py:188 -> measurement.py:205-210): a
+    vti_amd.FrameFeeder ring of pinned staging buffers, the H2D copy of batch k+1 on a copy stream under the compute of batch k.
+    PCIe-inclusive, therefore never the headline `value` (which the contract defines with inputs resident in HBM)."""
+    feeder = vti_amd.FrameFeeder(B, H, W, depth=3, device=dev)
+    host = frames.cpu().numpy()
+    for sl in range(feeder.depth):
+        feeder.host_view(sl)[:] = host                       # the "camera" has filled every staging buffer
+    outs = [eng.alloc_outputs(B, MAX_DET, cap, "bits", dev) for _ in range(2)]
+
+    def run(n):
+        nxt = feeder.submit(feeder.next_slot())
+        for k in range(n):
+            cur = nxt
+            if k + 1 < n:
+                nxt = feeder.submit(feeder.next_slot())      # next batch's copy goes out before this batch's kernels are enqueued
+            o = outs[k & 1]
+            x = feeder.frames(cur)
+            eng.forward(x, True, pred=o["pred"], proto=o["proto"], best=o["best"])
+            feeder.release(cur)
+            eng.nms(o["pred"], CONF, IOU, MAX_DET, False, dets=o["dets"], counts=o["counts"], best=o["best"])
+            eng.masks(o["dets"], o["counts"], o["proto"], "logit", "bits", capacity=cap, masks=o["masks"], offsets=o["offsets"])
+            eng.scale_boxes(o["dets"], o["counts"], H, W, xyxy=o["xyxy"])
+        torch.cuda.synchronize()
+    run(max(2, warmup))
+    t0 = time.perf_counter()
+    run(steps)
+    dt = time.perf_counter() - t0
+    return dict(value=round(B * steps / dt, 1), unit="frames/s", steps=steps, ms_per_step=round(dt / steps * 1e3, 4),
+                h2d_gb_per_s=round(B * H * W * 3 * steps / dt / 1e9, 2),
+                note="frames start in pinned host memory: vti_amd.FrameFeeder (3-slot ring, async H2D on a copy stream, event-chained into the "
+                     "predict kernels); PCIe-inclusive rate, not the headline")
 
 
 DTYPE_TAG = {"h2": "f16x2", "fp16": "f16", "fp32": "f32"}
@@ -298,6 +333,7 @@ def main():
     ap.add_argument("--preheat", type=float, default=1.0, help="seconds of untimed steps before the warm-up steps (clock settling)")
     ap.add_argument("--parity-frames", type=int, default=8, help="bench frames checked against the fp32 CPU oracle after the timed region (0: skip)")
     ap.add_argument("--no-fp32-line", action="store_true", help="skip the secondary fp32-engine measurement + parity")
+    ap.add_argument("--no-host-fed", action="store_true", help="skip the secondary measurement with frames starting in (pinned) host memory")
     ap.add_argument("--no-fp16-line", action="store_true", help="skip the secondary plain-fp16-engine measurement + parity")
     ap.add_argument("--pipeline", action="store_true",
                     help="overlap post-processing of batch k-1 with the network of batch k on a second stream: ~6 %% more frames/s "
@@ -511,6 +547,8 @@ def main():
             line["parity"] = parity_check(eng, blob, frames, nc, H, W, min(args.parity_frames, B))
             line["parity"]["engine"] = line["dtype"]
             line["parity"]["tolerance"] = "north_star gate: mask IoU >= 0.999 for every instance and |d box| < 1e-3 (normalised by 640) with the same kept set and order: see meets_north_star"
+        if world == 1 and not args.no_host_fed:
+            line["host_fed"] = host_fed_line(vti_amd, eng, frames, B, H, W, cap, dev, args.steps, args.warmup)
         for other, skip in (("fp16", args.no_fp16_line), ("fp32", args.no_fp32_line)):
             if world == 1 and other != args.dtype and not skip:
                 line[other + "_engine"] = other_engine_line(vti_amd, other, blob, frames, B, H, W, nc, cap, dev, min(args.parity_frames, B), args.steps, args.warmup)

@@ -148,6 +148,30 @@ def test_predict_batch_640_and_empty_results():
     assert len(quiet[0].boxes) == 0 and quiet[0].masks is None and quiet[0].boxes.xyxy.shape == (0, 4)
 
 
+def test_drop_empty_masks_flag_and_output_reuse():
+    """Newer Ultralytics releases drop instances whose thresholded mask is empty (`keep = masks.sum((-2, -1)) > 0` at the end of
+    the segmentation predictor; the reference reads the result at measurement.py:208-211 either way); `drop_empty_masks=True`
+    reproduces that: exactly the rows with a non-empty mask survive, in order.  Also: predict() reuses one cached output set across
+    calls, so Results of an earlier call must not change when a later call overwrites it."""
+    need_gpu()
+    import vti_amd
+    fr = frames_u8(2, 640, 640, seed=41)
+    base = _calibrated_model(vti_amd, 80, "h2", fr[0], 640, 0.25, target=300)
+    plain = base.predict(fr, conf=0.25, iou=0.7)
+    snap = [(r.boxes.data.clone(), r.masks.data_u8.clone()) for r in plain]
+    drop = vti_amd.YOLO(base._blob, dtype="h2", max_batch=2, drop_empty_masks=True).predict(fr, conf=0.25, iou=0.7)
+    again = base.predict(fr[::-1].copy(), conf=0.25, iou=0.7)              # overwrites the cached output set of `base`
+    n_empty = 0
+    for r, (bx, mk), d in zip(plain, snap, drop):
+        assert torch.equal(r.boxes.data, bx) and torch.equal(r.masks.data_u8, mk)          # earlier Results are copies
+        keep = mk.flatten(1).any(1)
+        n_empty += int((~keep).sum())
+        assert len(d.boxes) == int(keep.sum())
+        assert torch.equal(d.boxes.data, bx[keep]) and torch.equal(d.masks.data_u8, mk[keep])
+    assert torch.equal(again[1].boxes.data, snap[0][0])
+    print("empty masks dropped:", n_empty)
+
+
 def test_predict_errors_raise_not_abort():
     need_gpu()
     import vti_amd

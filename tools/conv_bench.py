@@ -34,6 +34,7 @@ def main():
     flt = sys.argv[1] if len(sys.argv) > 1 else ""
     iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20
     force = [int(v) for v in sys.argv[3:7]] if len(sys.argv) >= 7 else [0, 0, 0, 0]
+    DT = os.environ.get("VTI_BENCH_DTYPE", "fp16")
     B = 64
     rng = np.random.default_rng(0)
     for name, (c1, c2, k, s, kind, H, W) in SHAPES.items():
@@ -42,10 +43,11 @@ def main():
         if c1 == 3:
             x = torch.randint(0, 256, (B, H, W, 3), dtype=torch.uint8, device="cuda")
         else:
-            x = torch.randn((B, H, W, c1), device="cuda").half()
+            x = torch.randn((B, H, W, c1), device="cuda")
+            x = vti_amd.h2_encode(x.cpu()).cuda() if DT == "h2" else x.half() if DT == "fp16" else x
         w = (rng.standard_normal((c1, c2, k, k) if kind == 2 else (c2, c1, k, k)) / np.sqrt(c1 * k * k)).astype(np.float32)
         b = np.zeros(c2, np.float32)
-        out, ms, cfg = vti_amd.debug_conv2d(x, w, b, k, s, kind, "fp16", c1=c1, tile=(force[0], force[1]), waves_n=force[2], nrep=force[3], iters=iters)
+        out, ms, cfg = vti_amd.debug_conv2d(x, w, b, k, s, kind, DT, c1=c1, tile=(force[0], force[1]), waves_n=force[2], nrep=force[3], iters=iters)
         Ho, Wo = out.shape[1], out.shape[2]
         macs = (H * W if kind == 2 else Ho * Wo) * c1 * c2 * k * k * B
         byts = x.numel() * x.element_size() + out.numel() * out.element_size()

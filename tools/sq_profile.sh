@@ -1,11 +1,11 @@
 #!/bin/bash
 # Per kernel instantiation of a single-stream bs=64 forward + one post-processing step: where the SIMD cycles go (rocprofv3 PMC, two passes).
-#   bash tools/sq_profile.sh [tag]  ->  gpurun_out/profiles/<tag>_sq_profile.txt
+#   bash tools/sq_profile.sh [tag] [dtype=h2]  ->  gpurun_out/profiles/<tag>_sq_profile.txt
 tag=${1:-r02}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/profiles; mkdir -p $out
 export VTI_SINGLE_STREAM=1
-args="bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-fp32-line --parity-frames 0 --preheat 0"
+args="bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-fp32-line --no-host-fed --no-fp16-line --parity-frames 0 --preheat 0 --dtype ${2:-h2}"
 rm -rf gpurun_out/_sq1 gpurun_out/_sq2
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU --output-format csv -d gpurun_out/_sq1 -- python3 $args > /dev/null 2> gpurun_out/_sq1.err || exit 1
 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_MFMA --output-format csv -d gpurun_out/_sq2 -- python3 $args > /dev/null 2> gpurun_out/_sq2.err || exit 1
@@ -13,8 +13,8 @@ python3 - "$tag" <<'PY'
 import csv, glob, collections, re, sys
 tag = sys.argv[1]
 def short(n):
-    m = re.search(r"vti\d*(\w+?)I(DF16_|f)((?:L[ib]\d+E)*)", n)
-    if m: return m.group(1) + "<" + ("h" if m.group(2) != "f" else "f") + "," + ",".join(re.findall(r"L[ib](\d+)E", m.group(3))) + ">"
+    m = re.search(r"vti\d*(\w+?)I(DF16_|f|NS_4h2_tE)((?:L[ib]\d+E)*)", n)
+    if m: return m.group(1) + "<" + {"DF16_": "h", "f": "f"}.get(m.group(2), "h2") + "," + ",".join(re.findall(r"L[ib](\d+)E", m.group(3))) + ">"
     m = re.search(r"vti::(\w+)", n)
     return m.group(1) if m else n[:40]
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
@@ -26,7 +26,7 @@ for d in ("gpurun_out/_sq1", "gpurun_out/_sq2"):
         name = r["Counter_Name"] + ("_2" if d.endswith("2") and r["Counter_Name"] == "SQ_BUSY_CYCLES" else "")
         acc[k][name] += float(r["Counter_Value"])
         if r["Counter_Name"] == "SQ_BUSY_CYCLES" and d.endswith("1"): cnt[k] += 1
-L = ["rocprofv3 --pmc (two passes) -- python3 bench.py --steps 2 --warmup 1 ...   (VTI_SINGLE_STREAM=1, bs=64 fp16; sums over all launches of a kernel instantiation)",
+L = ["rocprofv3 --pmc (two passes) -- python3 bench.py --steps 2 --warmup 1 ...   (VTI_SINGLE_STREAM=1, bs=64; sums over all launches of a kernel instantiation)",
      "kernel cycles per SIMD = SQ_BUSY_CYCLES / 32 (summed over the 32 shader engines); shares below are of those cycles:",
      "  valu = 4 * SQ_INSTS_VALU / 1024 SIMDs;  mfma = SQ_VALU_MFMA_BUSY_CYCLES / 1024;  lds = SQ_LDS_IDX_ACTIVE / 256 CUs (conf = bank-conflict share of it);",
      "  wait = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES (share of resident wave time spent on s_waitcnt)",

@@ -6,7 +6,8 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # VTI_LIB_VARIANT=stamps selects the diagnostic build (tools/ only); the product always loads libvti.so
-LIB_PATH = os.path.join(_HERE, "libvti_stamps.so" if os.environ.get("VTI_LIB_VARIANT") == "stamps" else "libvti.so")
+_VARIANT = os.environ.get("VTI_LIB_VARIANT", "")       # developer builds: "stamps" (in-kernel timing), experiment variants (csrc/Makefile: variant)
+LIB_PATH = os.path.join(_HERE, f"libvti_{_VARIANT}.so" if _VARIANT else "libvti.so")
 
 VTI_F16, VTI_F32, VTI_H2 = 0, 1, 2
 VTI_MASK_LOGIT, VTI_MASK_SIGMOID = 0, 1

@@ -181,6 +181,12 @@ __global__ __launch_bounds__(NT, NT == 512 ? 1 : 2) void conv_kernel(const ConvP
                 for (int n = 0; n < NREP; ++n)
                     w[n] = *(const vec*)(smB + ((wn * NREP + n) * TAPS + tp) * 1024 + lane * 16);
             };
+            // (h2_taps keeps two prepared operand sets: 16 NREP registers more than the plain loop, which spills at NREP = 5 and at
+            // NREP = 4 with 256 threads -- those keep the plain loop, whose v_perms sit in front of each tap's MFMAs)
+            if constexpr (Tr<T>::H2 && TAPS > 1 && (NREP <= 3 || (NREP == 4 && NT == 512))) {
+                auto ldw1 = [&](int tp, int n) -> vec { return *(const vec*)(smB + ((wn * NREP + n) * TAPS + tp) * 1024 + lane * 16); };
+                h2_taps<NREP, MREP, TAPS, 3>(acc, ldx, ldw1);
+            } else {
             ldw(0, wq[0]);
             xq[0] = ldx(0);
             if (XD > 2 && NSTEP > 1) xq[1] = ldx(1);
@@ -194,6 +200,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? 1 : 2) void conv_kernel(const ConvP
                 for (int n = 0; n < NREP; ++n) acc[mm][n] = mma(wq[tp % WD][n], xq[s_ % XD], acc[mm][n]);
                 __builtin_amdgcn_sched_barrier(0);
                 if (WD == 1 && mm == MREP - 1 && tp + 1 < TAPS) ldw(tp + 1, wq[0]);   // reload after the tap's last use
+            }
             }
         }
         if (c < 2) VTI_STAMP(5 + 5 * c);
@@ -340,6 +347,10 @@ __global__ __launch_bounds__(256, 2) void convfold_kernel(const ConvParams p) {
 #pragma unroll
                 for (int n = 0; n < NREP; ++n) w[n] = *(const vec*)(smB + ((wave * NREP + n) * TAPS + tp) * 1024 + lane * 16);
             };
+            if constexpr (Tr<T>::H2) {
+                auto ldw1 = [&](int tp, int n) -> vec { return *(const vec*)(smB + ((wave * NREP + n) * TAPS + tp) * 1024 + lane * 16); };
+                h2_taps<NREP, MREP, TAPS, 3>(acc, ldx, ldw1);
+            } else {
             ldw(0, wq[0]);
             xq[0] = ldx(0);
             xq[1] = ldx(1);
@@ -352,6 +363,7 @@ __global__ __launch_bounds__(256, 2) void convfold_kernel(const ConvParams p) {
 #pragma unroll
                 for (int n = 0; n < NREP; ++n) acc[mm][n] = mma(wq[tp % 2][n], xq[s_ % 3], acc[mm][n]);
                 __builtin_amdgcn_sched_barrier(0);
+            }
             }
         }
         if (c + 1 < p.nchunks) __syncthreads();

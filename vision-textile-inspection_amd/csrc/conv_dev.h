@@ -29,15 +29,18 @@ template <> struct Tr<half_t> { typedef half8 vec; static constexpr int VEC = 8,
 template <> struct Tr<float> { typedef f32x4 vec; static constexpr int VEC = 4, KC = 16; static constexpr bool H16 = false, F32 = true, H2 = false; };
 template <> struct Tr<h2_t> { typedef h2x4 vec; static constexpr int VEC = 4, KC = 16; static constexpr bool H16 = false, F32 = false, H2 = true; };
 
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+// Written as explicit fmas so that each half is ONE instruction (v_fma_mixlo_f16 / v_fma_mixhi_f16 with the fp16 hi as the fp16
+// addend: v * 16 - hi is exact in f32, then rounded to fp16) -- the plain casts cost six (the file is compiled -ffp-contract=off).
 __device__ __forceinline__ unsigned h2_enc(float v) {
-    const float s = v * H2_SX;
-    const half_t hi = (half_t)s;
-    const half_t lo = (half_t)(s - (float)hi);
-    return (unsigned)__builtin_bit_cast(unsigned short, hi) | ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
+    half2v p;
+    p[0] = (half_t)__builtin_fmaf(v, H2_SX, 0.0f);
+    p[1] = (half_t)__builtin_fmaf(v, H2_SX, -(float)p[0]);
+    return __builtin_bit_cast(unsigned, p);
 }
 __device__ __forceinline__ float h2_dec(unsigned u) {
-    const half_t hi = __builtin_bit_cast(half_t, (unsigned short)(u & 0xffffu)), lo = __builtin_bit_cast(half_t, (unsigned short)(u >> 16));
-    return ((float)hi + (float)lo) * (1.0f / H2_SX);      // hi + lo is exact in f32 (<= 24 significant bits)
+    const half2v p = __builtin_bit_cast(half2v, u);
+    return ((float)p[0] + (float)p[1]) * (1.0f / H2_SX);      // hi + lo is exact in f32 (<= 24 significant bits)
 }
 // one element from a float; element j of an operand vector
 template <typename T> __device__ __forceinline__ T to_T(float v) {
@@ -78,18 +81,87 @@ __device__ __forceinline__ f32x4 mma(f32x4 w, f32x4 x, f32x4 c) {
 
 // h2: the weight fragment holds (hi | lo << 16) pairs of 4 channels; the pixel fragment the same.  With WH = the hi halves
 // duplicated into both halves of each dword and WL = the lo halves duplicated,
-//   mfma(WH, X) = sum wh * (xh + xl),  mfma(WL, X) = sum wl * (xh + xl):  all four partial products, fp32 accumulation.
+//   mfma(WH, X) = sum wh * (xh + xl),  mfma(WL, X) = sum wl * xh  with WL = (lo, 0):  fp32 accumulation; wl * xl (< 2^-22) is dropped.
 __device__ __forceinline__ f32x4 mma(h2x4 w, h2x4 x, f32x4 c) {
     u32x4 wh, wl;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         wh[i] = __builtin_amdgcn_perm(w.u[i], w.u[i], 0x01000100u);
-        wl[i] = __builtin_amdgcn_perm(w.u[i], w.u[i], 0x03020302u);
+        wl[i] = w.u[i] >> 16;
     }
     const half8 xv = __builtin_bit_cast(half8, x.u);
     c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, wh), xv, c, 0, 0, 0);
     c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, wl), xv, c, 0, 0, 0);
     return c;
+}
+
+// The MFMA loop of one K chunk for h2, over the flat (tap, pixel-tile) sequence of a wave's M x NREP register tile (the loop every
+// 3x3 kernel runs; ldx(s) reads the pixel fragment of step s = tap * M + m, ldw(tap, n) the raw weight fragment of n-tile n).
+// Same software pipeline as the fp16 / fp32 loops -- pixel fragments XD steps ahead, the next tap's weights one tap ahead -- plus
+// what h2 needs: a raw fragment (hi | lo << 16 pairs) becomes the two MFMA operands WH = (hi, hi) / WL = (lo, 0) by 8 VALU
+// instructions.  (WL faces xh only: the wl * xl products are below 2^-22 of the sum, and with zeros in half of the second MFMA's
+// multipliers the chip holds a higher clock under this loop -- 120 -> 113 us on the 64 -> 64 layer at 80x80, A/B on one box.)  Done where the
+// fragment is used, those 8 * NREP instructions per tap run in the open (measured: 16 perms in front of every 20 MFMAs at NREP = 2);
+// here the NEXT tap's fragments are prepared one v_perm per MFMA in steps 1 .. M-1 of the current tap, where they issue in the
+// matrix pipe's shadow (an MFMA blocks vector issue for 8 of its 16 cycles).
+template <int NREP, int M, int TAPS, int XD, class LDX, class LDW>
+__device__ __forceinline__ void h2_taps(f32x4 (&acc)[M][NREP], LDX ldx, LDW ldw) {
+    constexpr int NSTEP = TAPS * M;
+    constexpr unsigned SEL_H = 0x01000100u;
+    h2x4 xq[XD];
+    u32x4 wraw[NREP];
+    u32x4 wh[2][NREP], wl[2][NREP];                     // prepared operands of the current / next tap (by tap parity)
+#pragma unroll
+    for (int n = 0; n < NREP; ++n) wraw[n] = ldw(0, n).u;
+#pragma unroll
+    for (int i = 0; i < XD - 1; ++i) xq[i] = ldx(i);
+#pragma unroll
+    for (int n = 0; n < NREP; ++n)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            wh[0][n][i] = __builtin_amdgcn_perm(wraw[n][i], wraw[n][i], SEL_H);
+            wl[0][n][i] = wraw[n][i] >> 16;
+        }
+#pragma unroll
+    for (int s_ = 0; s_ < NSTEP; ++s_) {
+        const int tp = s_ / M, mm = s_ % M, cur = tp & 1, nxt = cur ^ 1;
+#ifdef H2_EXP_NOXREAD       // experiment (tools/ variants only): how much of a step is the pixel-fragment LDS read
+        if (s_ + XD - 1 < NSTEP && s_ < XD) xq[(s_ + XD - 1) % XD] = ldx(s_ + XD - 1);
+#else
+        if (s_ + XD - 1 < NSTEP) xq[(s_ + XD - 1) % XD] = ldx(s_ + XD - 1);
+#endif
+        if (mm == 0 && tp + 1 < TAPS) {
+#pragma unroll
+            for (int n = 0; n < NREP; ++n) wraw[n] = ldw(tp + 1, n).u;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const half8 xv = __builtin_bit_cast(half8, xq[s_ % XD].u);
+#pragma unroll
+        for (int j = 0; j < 2 * NREP; ++j) {
+            const int n = j >> 1;
+#ifdef H2_EXP_SKIP          // experiment (wrong results): every other tap runs without its WL MFMA = 3 MFMAs per 32 channel-taps
+            if (!((j & 1) && (tp & 1)))
+#endif
+            acc[mm][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, (j & 1) ? wl[cur][n] : wh[cur][n]), xv, acc[mm][n], 0, 0, 0);
+            const int k = (mm - 1) * 2 * NREP + j;      // this MFMA's share of the next tap's preparation
+#ifdef H2_EXP_NOPERM         // experiment: next tap's operands = the raw fragments (wrong results), no v_perm
+            if (mm == 1 && j == 0 && tp + 1 < TAPS) {
+#pragma unroll
+                for (int n2 = 0; n2 < NREP; ++n2) { wh[nxt][n2] = wraw[n2]; wl[nxt][n2] = wraw[n2]; }
+            }
+            if (false) {
+#else
+            if (mm >= 1 && k < 8 * NREP && tp + 1 < TAPS) {
+#endif
+                const int pn = k >> 3, r = k & 7, i = r & 3;
+                if (r < 4) wh[nxt][pn][i] = __builtin_amdgcn_perm(wraw[pn][i], wraw[pn][i], SEL_H);
+                else wl[nxt][pn][i] = wraw[pn][i] >> 16;
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA, then one VALU: keep the interleave
+                __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
 }
 
 // SiLU.  fp32 engine (parity mode): IEEE exp + division, as the CPU reference computes it.
@@ -126,12 +198,18 @@ constexpr int MREP = 5;
 // Diagnostic build (make STAMPS=1 -> libvti_stamps.so, used only by tools/): s_memtime stamps of
 // workgroup phases, written by wave 0 to a buffer nothing else reads.  Compiled out of the product.
 #ifdef VTI_STAMPS
+// slots 0 and 12 (start / end of the workgroup) also record s_memrealtime (100 MHz) in slots 14 / 15: the in-kernel shader clock is
+// (t12 - t0) / (rt15 - rt14) x 100 MHz (MI355X_MICROARCH.md, DVFS give-back item 6)
 #define VTI_STAMP(i)                                                                              \
     do {                                                                                          \
         if (p.stamps && tid == 0) {                                                               \
             unsigned long long t_;                                                                \
             asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");            \
             p.stamps[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 + (i)] = t_;              \
+            if ((i) == 0 || (i) == 12) {                                                          \
+                asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");    \
+                p.stamps[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 + ((i) == 0 ? 14 : 15)] = t_; \
+            }                                                                                     \
         }                                                                                         \
     } while (0)
 #else

@@ -15,7 +15,8 @@
 //    step's MFMAs (so the stage about to be refilled has no readers left).  Compute waves never wait on vmcnt: their
 //    stores stay in flight.  (Issuing a 1-KiB DMA piece costs the issuing wave ~130 cycles; with one compute wave per
 //    SIMD that cost has to live in other waves.)
-//  * Weights of a conv with K <= 2 chunks are loaded ONCE per workgroup and stay in LDS for all its tiles.
+//  * Weights of a conv with K <= 2 chunks -- or of any conv whose planner found LDS room for all chunks of a workgroup's n-group
+//    (pk_wstat: typically after splitting N across workgroups) -- are loaded ONCE per workgroup and stay in LDS for all its tiles.
 //  * LDS patch image: pixel-major, one 64-byte slot per pixel and chunk, 24 slots per patch row (20-wide tiles
 //    + halo, padded to a multiple of 8).  A DMA wave-instruction fills 16 consecutive slots from 16 pixels x 64
 //    contiguous bytes of global memory (4 lanes per pixel: whole 64-B segments, not 16-B fragments).  The 16-byte
@@ -41,58 +42,59 @@ constexpr int PK_MAXD2 = 13;      // ... of the stride-2 kernel (its patch is ~4
 // `depth` patch stages (2..4): the loaders run depth - 1 steps ahead.  Weights: K <= 2 chunks stay resident (1 or 2 buffers);
 // more chunks travel with the patches, one buffer per stage.
 static size_t pk_stage_bytes(int TH, int S) { return S == 2 ? (size_t)(2 * TH + 1) * 2 * PK_PWP * 64 : (size_t)(TH + 2) * PK_PWP * 64; }
-size_t conv_pk2_lds_bytes(int TH, int WN, int NREP, int nchunks, int depth) {     // stride 2
-    const int nwbuf = nchunks > 2 ? depth : (nchunks > 1 ? 2 : 1);
+// wstat: the weights of ALL K chunks of the workgroup's n-group stay in LDS (any chunk count; K <= 2 chunks are always resident)
+size_t conv_pk2_lds_bytes(int TH, int WN, int NREP, int nchunks, int depth, int wstat) {     // stride 2
+    const int nwbuf = wstat ? nchunks : nchunks > 2 ? depth : (nchunks > 1 ? 2 : 1);
     return depth * pk_stage_bytes(TH, 2) + (size_t)nwbuf * WN * NREP * 9 * 1024 + (size_t)WN * NREP * 16 * 4;
 }
 bool conv_pk2_instantiated(int nrep, int wn) { return (nrep == 1 && wn == 4) || (nrep == 2 && wn == 2) || (nrep == 4 && wn == 1) || (nrep == 2 && wn == 1) || (nrep == 1 && wn == 2); }
-bool conv_pk2_fits(int TH, int WN, int NREP, int nchunks) {
+bool conv_pk2_fits(int TH, int WN, int NREP, int nchunks, int wstat) {
     if (TH % PK_ROWS || !conv_pk2_instantiated(NREP, WN)) return false;
     const int ncomp = (TH / PK_ROWS) * WN;
     if (ncomp < 1 || ncomp > 4) return false;
     const int ndma = (int)(pk_stage_bytes(TH, 2) / 1024);
     if ((ndma + ncomp - 1) / ncomp > PK_MAXD2) return false;
-    return conv_pk2_lds_bytes(TH, WN, NREP, nchunks, 2) <= 160 * 1024;
+    return conv_pk2_lds_bytes(TH, WN, NREP, nchunks, 2, wstat) <= 160 * 1024;
 }
-int conv_pk2_depth(int TH, int WN, int NREP, int nchunks) {
-    if (!conv_pk2_fits(TH, WN, NREP, nchunks)) return 0;
+int conv_pk2_depth(int TH, int WN, int NREP, int nchunks, int wstat) {
+    if (!conv_pk2_fits(TH, WN, NREP, nchunks, wstat)) return 0;
     // default 2: in an A/B on one box the deeper rings made the whole forward ~0.7 % SLOWER (VTI_PK_DEPTH=3/4 to re-measure)
     const char* cap = getenv("VTI_PK_DEPTH");
     const int maxd = cap ? std::max(2, std::min(4, atoi(cap))) : 2;
     const int ncomp = (TH / PK_ROWS) * WN;
-    const int per_step = ((int)(pk_stage_bytes(TH, 2) / 1024) + ncomp - 1) / ncomp + (nchunks > 2 ? (WN * NREP * 9 + ncomp - 1) / ncomp : 0);
+    const int per_step = ((int)(pk_stage_bytes(TH, 2) / 1024) + ncomp - 1) / ncomp + (nchunks > 2 && !wstat ? (WN * NREP * 9 + ncomp - 1) / ncomp : 0);
     int d = 2;
-    while (d < maxd && conv_pk2_lds_bytes(TH, WN, NREP, nchunks, d + 1) <= 160 * 1024 && per_step * (d - 1) <= 63) ++d;
+    while (d < maxd && conv_pk2_lds_bytes(TH, WN, NREP, nchunks, d + 1, wstat) <= 160 * 1024 && per_step * (d - 1) <= 63) ++d;
     return d;
 }
 
-size_t conv_pk_lds_bytes(int TH, int WN, int NREP, int nchunks, int depth) {
+size_t conv_pk_lds_bytes(int TH, int WN, int NREP, int nchunks, int depth, int wstat) {
     const size_t stage = (size_t)(TH + 2) * PK_PWP * 64;
-    const int nwbuf = nchunks > 2 ? depth : (nchunks > 1 ? 2 : 1);
+    const int nwbuf = wstat ? nchunks : nchunks > 2 ? depth : (nchunks > 1 ? 2 : 1);
     return depth * stage + (size_t)nwbuf * WN * NREP * 9 * 1024 + (size_t)WN * NREP * 16 * 4;
 }
-size_t conv_pk_lds_bytes(int TH, int WN, int NREP, int nchunks) { return conv_pk_lds_bytes(TH, WN, NREP, nchunks, 2); }
+size_t conv_pk_lds_bytes(int TH, int WN, int NREP, int nchunks) { return conv_pk_lds_bytes(TH, WN, NREP, nchunks, 2, 0); }
 
 // deepest ring (<= 4) that fits the 160 KiB of LDS and the counted-wait range; 0 = the geometry does not fit at all
-int conv_pk_depth(int TH, int WN, int NREP, int nchunks) {
-    if (!conv_pk_fits(TH, WN, NREP, nchunks)) return 0;
+int conv_pk_depth(int TH, int WN, int NREP, int nchunks, int wstat) {
+    if (!conv_pk_fits(TH, WN, NREP, nchunks, wstat)) return 0;
     // default 2: in an A/B on one box the deeper rings made the whole forward ~0.7 % SLOWER (VTI_PK_DEPTH=3/4 to re-measure)
     const char* cap = getenv("VTI_PK_DEPTH");
     const int maxd = cap ? std::max(2, std::min(4, atoi(cap))) : 2;
     const int ncomp = (TH / PK_ROWS) * WN;
-    const int per_step = ((TH + 2) * PK_PWP / 16 + ncomp - 1) / ncomp + (nchunks > 2 ? (WN * NREP * 9 + ncomp - 1) / ncomp : 0);
+    const int per_step = ((TH + 2) * PK_PWP / 16 + ncomp - 1) / ncomp + (nchunks > 2 && !wstat ? (WN * NREP * 9 + ncomp - 1) / ncomp : 0);
     int d = 2;
-    while (d < maxd && conv_pk_lds_bytes(TH, WN, NREP, nchunks, d + 1) <= 160 * 1024 && per_step * (d - 1) <= 63) ++d;
+    while (d < maxd && conv_pk_lds_bytes(TH, WN, NREP, nchunks, d + 1, wstat) <= 160 * 1024 && per_step * (d - 1) <= 63) ++d;
     return d;
 }
 
-bool conv_pk_fits(int TH, int WN, int NREP, int nchunks) {
+bool conv_pk_fits(int TH, int WN, int NREP, int nchunks, int wstat) {
     if (TH % PK_ROWS) return false;
     const int ncomp = (TH / PK_ROWS) * WN;        // compute waves; as many loader waves beside them
     if (ncomp < 1 || ncomp > 4) return false;
     const int ndma = (TH + 2) * PK_PWP / 16;
     if ((ndma + ncomp - 1) / ncomp > PK_MAXD) return false;
-    return conv_pk_lds_bytes(TH, WN, NREP, nchunks) <= 160 * 1024;
+    return conv_pk_lds_bytes(TH, WN, NREP, nchunks, 2, wstat) <= 160 * 1024;
 }
 
 // LDS-DMA: 64 lanes x 16 B from per-lane buffer offsets to LDS [lds_addr, lds_addr + 1 KiB), lane-linear.
@@ -137,9 +139,9 @@ __global__ __launch_bounds__(512) void conv3_pk(const ConvParams p) {
     const int stage_bytes = PH * PWP * 64;
     const int ndma = PH * PWP / 16;
     const int D = p.pk_depth;                               // patch stages (ring depth)
-    const bool stream_w = p.nchunks > 2;
+    const bool stream_w = p.nchunks > 2 && !p.pk_wstat;        // pk_wstat: all chunks of this n-group resident (the planner found room)
     const int wbuf_off = D * stage_bytes;
-    const int bias_off = wbuf_off + (stream_w ? D : (p.nchunks > 1 ? 2 : 1)) * WCHUNK;
+    const int bias_off = wbuf_off + (stream_w ? D : p.nchunks) * WCHUNK;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
     const int nt0 = blockIdx.y * NTB;
 
@@ -237,9 +239,11 @@ __global__ __launch_bounds__(512) void conv3_pk(const ConvParams p) {
         // chunk 1's resident weights go out AFTER the first patches: step 0 starts as soon as chunk 0's weights and patch(0) are in,
         // without waiting for the second half of the weights (36 of 72 KB on the 64-channel layers: ~2 k cycles of every launch)
         int w1cnt = 0;
-        if (!stream_w && p.nchunks == 2) {
-            issue_weights(1, 1);
-            if (lw < NTB * TAPS) w1cnt = (NTB * TAPS - lw + nld - 1) / nld;
+        if (!stream_w) {
+            for (int c = 1; c < p.nchunks; ++c) {
+                issue_weights(c, c);
+                if (lw < NTB * TAPS) w1cnt += (NTB * TAPS - lw + nld - 1) / nld;
+            }
         }
         for (int s = 0; s < nsteps; ++s) {
             const int inflight = min(D - 2, nsteps - 1 - s);
@@ -314,6 +318,13 @@ __global__ __launch_bounds__(512) void conv3_pk(const ConvParams p) {
 #pragma unroll
                     for (int n = 0; n < NREP; ++n) w[n] = *(const vec*)(sw + (n * TAPS + tp) * 1024);
                 };
+                if constexpr (Tr<T>::H2) {
+                    auto ldw1 = [&](int tp, int n) -> vec { return *(const vec*)(sw + (n * TAPS + tp) * 1024); };
+#ifndef H2_XD
+#define H2_XD (NREP >= 4 ? 3 : 4)
+#endif
+                    h2_taps<NREP, MREP, TAPS, H2_XD>(acc, ldx, ldw1);
+                } else {
                 ldw(0, wq[0]);
 #pragma unroll
                 for (int i = 0; i < XD - 1; ++i) xq[i] = ldx(i);
@@ -326,6 +337,7 @@ __global__ __launch_bounds__(512) void conv3_pk(const ConvParams p) {
 #pragma unroll
                     for (int n = 0; n < NREP; ++n) acc[mm][n] = mma(wq[tp % WD][n], xq[s_ % XD], acc[mm][n]);
                     __builtin_amdgcn_sched_barrier(0);
+                }
                 }
             }
             if (step < 2) VTI_STAMP(3 + 4 * step);
@@ -797,8 +809,8 @@ hipError_t launch_conv_pk_fold(int dtype, const ConvParams& p, size_t lds_bytes,
 // stride-2 3x3 on the persistent schedule (p.pk == 4)
 hipError_t launch_conv_pk2(int dtype, int nrep, const ConvParams& p, size_t lds_bytes, hipStream_t st) {
     const int NTB = p.WN * nrep;
-    if (p.TW != PK_TW || !conv_pk2_fits(p.TH, p.WN, nrep, p.nchunks) || p.ntiles2 > 0) return hipErrorInvalidValue;
-    if (p.pk_depth < 2 || p.pk_depth > 4 || lds_bytes < conv_pk2_lds_bytes(p.TH, p.WN, nrep, p.nchunks, p.pk_depth) || lds_bytes > 160 * 1024) return hipErrorInvalidValue;
+    if (p.TW != PK_TW || !conv_pk2_fits(p.TH, p.WN, nrep, p.nchunks, p.pk_wstat) || p.ntiles2 > 0) return hipErrorInvalidValue;
+    if (p.pk_depth < 2 || p.pk_depth > 4 || lds_bytes < conv_pk2_lds_bytes(p.TH, p.WN, nrep, p.nchunks, p.pk_depth, p.pk_wstat) || lds_bytes > 160 * 1024) return hipErrorInvalidValue;
     if (p.ntiles_n % NTB || p.pk_wgs < 1 || (p.pk_xcd && p.pk_wgs % 8)) return hipErrorInvalidValue;
     if ((size_t)p.in_bytes >= 0x80000000u || (size_t)p.out_bytes >= 0x80000000u) return hipErrorInvalidValue;
     if (p.pk_tiles == 0) return hipSuccess;
@@ -818,8 +830,8 @@ hipError_t launch_conv_pk2(int dtype, int nrep, const ConvParams& p, size_t lds_
 // grid.x workgroups (p.pk_wgs, a multiple of 8 when p.pk_xcd) x n-groups; (TH/4) * WN compute + as many loader waves
 hipError_t launch_conv_pk(int dtype, int nrep, const ConvParams& p, size_t lds_bytes, hipStream_t st) {
     const int NTB = p.WN * nrep;
-    if (p.TH % PK_ROWS || p.TW != PK_TW || !conv_pk_fits(p.TH, p.WN, nrep, p.nchunks)) return hipErrorInvalidValue;
-    if (p.pk_depth < 2 || p.pk_depth > 4 || lds_bytes < conv_pk_lds_bytes(p.TH, p.WN, nrep, p.nchunks, p.pk_depth) || lds_bytes > 160 * 1024) return hipErrorInvalidValue;
+    if (p.TH % PK_ROWS || p.TW != PK_TW || !conv_pk_fits(p.TH, p.WN, nrep, p.nchunks, p.pk_wstat)) return hipErrorInvalidValue;
+    if (p.pk_depth < 2 || p.pk_depth > 4 || lds_bytes < conv_pk_lds_bytes(p.TH, p.WN, nrep, p.nchunks, p.pk_depth, p.pk_wstat) || lds_bytes > 160 * 1024) return hipErrorInvalidValue;
     if (p.ntiles_n % NTB || p.pk_wgs < 1 || (p.pk_xcd && p.pk_wgs % 8)) return hipErrorInvalidValue;
     if ((size_t)p.in_bytes >= 0x80000000u || (size_t)p.out_bytes >= 0x80000000u) return hipErrorInvalidValue;
     if (p.pk_tiles == 0) return hipSuccess;
@@ -1072,6 +1084,10 @@ __global__ __launch_bounds__(512) void bneck_pk(const ConvParams p) {
 #pragma unroll
                 for (int n = 0; n < NREP; ++n) w[n] = *(const vec*)(sw + (n * TAPS + tp) * 1024);
             };
+            if constexpr (Tr<T>::H2) {
+                auto ldw1 = [&](int tp, int n) -> vec { return *(const vec*)(sw + (n * TAPS + tp) * 1024); };
+                h2_taps<NREP, BN_MREP1, TAPS, 4>(acc, ldx, ldw1);
+            } else {
             ldw(0, wq[0]);
 #pragma unroll
             for (int i = 0; i < XD - 1; ++i) xq[i] = ldx(i);
@@ -1084,6 +1100,7 @@ __global__ __launch_bounds__(512) void bneck_pk(const ConvParams p) {
 #pragma unroll
                 for (int n = 0; n < NREP; ++n) acc[mm][n] = mma(wq[tp % 2][n], xq[s_ % XD], acc[mm][n]);
                 __builtin_amdgcn_sched_barrier(0);
+            }
             }
             if (step == 2) VTI_STAMP(3);
             // bias + SiLU, rounded to T, into the T image; a pixel outside the feature map is conv 2's zero padding
@@ -1139,6 +1156,10 @@ __global__ __launch_bounds__(512) void bneck_pk(const ConvParams p) {
 #pragma unroll
                 for (int n = 0; n < NREP; ++n) w[n] = *(const vec*)(sw + (n * TAPS + tp) * 1024);
             };
+            if constexpr (Tr<T>::H2) {
+                auto ldw1 = [&](int tp, int n) -> vec { return *(const vec*)(sw + (n * TAPS + tp) * 1024); };
+                h2_taps<NREP, MREP, TAPS, 4>(acc, ldx, ldw1);
+            } else {
             ldw(0, wq[0]);
 #pragma unroll
             for (int i = 0; i < XD - 1; ++i) xq[i] = ldx(i);
@@ -1151,6 +1172,7 @@ __global__ __launch_bounds__(512) void bneck_pk(const ConvParams p) {
 #pragma unroll
                 for (int n = 0; n < NREP; ++n) acc[mm][n] = mma(wq[tp % 2][n], xq[s_ % XD], acc[mm][n]);
                 __builtin_amdgcn_sched_barrier(0);
+            }
             }
             if (step == 2) VTI_STAMP(6);
 #pragma unroll

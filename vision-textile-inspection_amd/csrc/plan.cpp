@@ -101,10 +101,20 @@ struct Builder {
 //  * compute: per tile and wave nchunks x 45 x NREP MFMAs of 16 cycles + ~1100 x NREP epilogue cycles, times the
 //    waves that share the busiest SIMD, times the rounds of tiles per workgroup slot, at ~1.9 GHz;
 //  * LDS operand reads per MFMA (1/NREP + 1/5) stretch the MFMA phase once they pass ~0.5.
-static bool choose_pk_cfg(int esize, const ConvRow& r, int max_batch, ConvCfg& c, int fth, int fwn, int fnrep) {
+// 4-byte storage (fp32 / h2): K chunks are 16 channels, so a layer has twice the chunks and twice the weight bytes of the fp16 engine and
+// its weights rarely fit beside the patches; streamed with every patch they are 60-70 % of a step's LDS-DMA bytes, and the L2 -> LDS ingest
+// (~4 TB/s over the chip, measured: every geometry of a 64 -> 64 layer at 40x40 takes the same 34 us) is what bounds these layers.  For
+// them the search also tries `wstat`: ALL chunks of a workgroup's n-group resident (which favours splitting N across workgroups: a
+// 2-tile slice of a 64 -> 64 layer is 72 KB), and prices the ingest: patches once per n-group + weights per tile (streamed) or per
+// workgroup (resident).
+static bool choose_pk_cfg(int dtype, const ConvRow& r, int max_batch, ConvCfg& c, int fth, int fwn, int fnrep) {
     const char* no = getenv("VTI_NO_PK");
     if (no && no[0] == '1') return false;
     if (!(r.k == 3 && r.s == 1 && r.kind != 2) || r.w_out < 20) return false;
+    const int esize = dtype == VTI_F16 ? 2 : 4;
+    const bool wide = dtype != VTI_F16;                        // 4-byte elements: ingest-priced search with resident-weight variants
+    const double mf = dtype == VTI_H2 ? 2.0 : dtype == VTI_F32 ? 8.0 : 1.0;      // matrix-pipe cycles per (n-tile, m-tile, tap) in units of 16
+    static const bool no_wstat = getenv("VTI_NO_PK_WSTAT") && getenv("VTI_NO_PK_WSTAT")[0] == '1';
     double best = 1e30;
     bool found = false;
     const int tiles_x = (r.w_out + 19) / 20;
@@ -120,26 +130,34 @@ static bool choose_pk_cfg(int esize, const ConvRow& r, int max_batch, ConvCfg& c
             for (int NWM = 1; NWM <= 4; ++NWM) {
                 const int TH = 4 * NWM, ncomp = NWM * WN;
                 if (fth && TH != fth) continue;
-                if (ncomp > 4 || !conv_pk_fits(TH, WN, NREP, c.nchunks)) continue;
-                const size_t lds = conv_pk_lds_bytes(TH, WN, NREP, c.nchunks);
-                const int wgpc = (int)std::min<size_t>(2, (160 * 1024) / lds);
-                const int tiles_y = (r.h_out + TH - 1) / TH;
-                const long NT = (long)max_batch * tiles_y * tiles_x;
-                long G = std::min<long>(NT, std::max(1, 256 * wgpc / gy));
-                if (G >= 8) G &= ~7L;
-                const long rounds = (NT + G - 1) / G;
-                const int simd_load = (ncomp * wgpc + 3) / 4;
-                const double lds_reads = 1.0 / NREP + 0.2;
-                // NREP = 5 keeps 100 accumulator registers and a shallow operand queue: measured 12 % behind two n-groups of 3
-                // (tools/pk_sweep.py: 64 -> 80 at 80 x 80: 61 vs 54 us), hence the factor (fitted so that the model flips where the sweep does)
-                const double mfma_cyc = (double)c.nchunks * 45 * NREP * 16 * std::max(1.0, lds_reads / 0.5) * (NREP == 5 ? 1.6 : 1.0);
-                const double t_comp = rounds * (mfma_cyc * simd_load + 1100.0 * NREP) / 1.9e9;   // a SIMD partner's MFMAs hide the epilogue
-                const double bytes = (double)NT * ((double)gy * (TH + 2) * 22 * r.c1 + (double)TH * 20 * r.c2) * esize;
-                const double t_mem = bytes / 5.0e12;
-                const double cost = std::max(t_comp, t_mem) + 0.15 * std::min(t_comp, t_mem) + 4e-6;
-                if (cost < best) {
-                    best = cost; found = true;
-                    c.TH = TH; c.TW = 20; c.WN = WN; c.NREP = NREP; c.lds = lds; c.pk = 1; c.pk_wgpc = wgpc;
+                for (int wstat = (wide && !no_wstat && c.nchunks > 2) ? 1 : 0; wstat >= 0; --wstat) {
+                    if (ncomp > 4 || !conv_pk_fits(TH, WN, NREP, c.nchunks, wstat)) continue;
+                    const size_t lds = conv_pk_lds_bytes(TH, WN, NREP, c.nchunks, 2, wstat);
+                    const int wgpc = (int)std::min<size_t>(2, (160 * 1024) / lds);
+                    const int tiles_y = (r.h_out + TH - 1) / TH;
+                    const long NT = (long)max_batch * tiles_y * tiles_x;
+                    long G = std::min<long>(NT, std::max(1, 256 * wgpc / gy));
+                    if (G >= 8) G &= ~7L;
+                    const long rounds = (NT + G - 1) / G;
+                    const int simd_load = (ncomp * wgpc + 3) / 4;
+                    const double lds_reads = (1.0 / NREP + 0.2) / mf;
+                    // NREP = 5 keeps 100 accumulator registers and a shallow operand queue: measured 12 % behind two n-groups of 3
+                    // (tools/pk_sweep.py: 64 -> 80 at 80 x 80: 61 vs 54 us), hence the factor (fitted so that the model flips where the sweep does)
+                    const double mfma_cyc = (double)c.nchunks * 45 * NREP * 16 * mf * std::max(1.0, lds_reads / 0.5) * (NREP == 5 ? 1.6 : 1.0);
+                    const double t_comp = rounds * (mfma_cyc * simd_load + 1100.0 * NREP) / 1.9e9;   // a SIMD partner's MFMAs hide the epilogue
+                    const double bytes = (double)NT * ((double)gy * (TH + 2) * 22 * r.c1 + (double)TH * 20 * r.c2) * esize;
+                    const double t_mem = bytes / 5.0e12;
+                    double t_ing = 0.0;
+                    if (wide) {
+                        const double patch = (double)(TH + 2) * 24 * 64 * c.nchunks, wbytes = (double)NTB * 9 * 1024 * c.nchunks;
+                        const bool resident = wstat || c.nchunks <= 2;
+                        t_ing = ((double)NT * gy * (patch + (resident ? 0.0 : wbytes)) + (resident ? (double)G * gy * wbytes : 0.0)) / 4.0e12;
+                    }
+                    const double cost = std::max(std::max(t_comp, t_mem), t_ing) + 0.15 * std::min(t_comp, t_mem) + 4e-6;
+                    if (cost < best) {
+                        best = cost; found = true;
+                        c.TH = TH; c.TW = 20; c.WN = WN; c.NREP = NREP; c.lds = lds; c.pk = 1; c.pk_wgpc = wgpc; c.pk_wstat = wstat;
+                    }
                 }
             }
         }
@@ -148,9 +166,9 @@ static bool choose_pk_cfg(int esize, const ConvRow& r, int max_batch, ConvCfg& c
         c.ntiles_n = (c.ntiles_n + c.WN * c.NREP - 1) / (c.WN * c.NREP) * (c.WN * c.NREP);   // whole workgroup n-groups
         // ring depth: a deeper ring (loaders further ahead) when it costs no co-resident workgroup
         c.pk_depth = 2;
-        const int dmax = conv_pk_depth(c.TH, c.WN, c.NREP, c.nchunks);
+        const int dmax = conv_pk_depth(c.TH, c.WN, c.NREP, c.nchunks, c.pk_wstat);
         for (int dd = 3; dd <= dmax; ++dd) {
-            const size_t l = conv_pk_lds_bytes(c.TH, c.WN, c.NREP, c.nchunks, dd);
+            const size_t l = conv_pk_lds_bytes(c.TH, c.WN, c.NREP, c.nchunks, dd, c.pk_wstat);
             if ((int)std::min<size_t>(2, (160 * 1024) / l) >= c.pk_wgpc) { c.pk_depth = dd; c.lds = l; }
         }
     }
@@ -158,10 +176,14 @@ static bool choose_pk_cfg(int esize, const ConvRow& r, int max_batch, ConvCfg& c
 }
 
 // Stride-2 3x3 convs on the persistent schedule (conv3_pk<..., S = 2>): same cost model, the patch is (2 TH + 1) x 41 input pixels.
-static bool choose_pk2_cfg(int esize, const ConvRow& r, int max_batch, ConvCfg& c, int fth, int fwn, int fnrep) {
+static bool choose_pk2_cfg(int dtype, const ConvRow& r, int max_batch, ConvCfg& c, int fth, int fwn, int fnrep) {
     const char* no = getenv("VTI_NO_PK2");
     if (no && no[0] == '1') return false;
     if (!(r.k == 3 && r.s == 2 && r.kind == 0) || r.w_out < 20) return false;
+    const int esize = dtype == VTI_F16 ? 2 : 4;
+    const bool wide = dtype != VTI_F16;
+    const double mf = dtype == VTI_H2 ? 2.0 : dtype == VTI_F32 ? 8.0 : 1.0;
+    static const bool no_wstat = getenv("VTI_NO_PK_WSTAT") && getenv("VTI_NO_PK_WSTAT")[0] == '1';
     double best = 1e30;
     bool found = false;
     const int tiles_x = (r.w_out + 19) / 20;
@@ -177,30 +199,38 @@ static bool choose_pk2_cfg(int esize, const ConvRow& r, int max_batch, ConvCfg& 
             for (int NWM = 1; NWM <= 4; ++NWM) {
                 const int TH = 4 * NWM, ncomp = NWM * WN;
                 if (fth && TH != fth) continue;
-                if (ncomp > 4 || !conv_pk2_fits(TH, WN, NREP, c.nchunks)) continue;
-                const int tiles_y = (r.h_out + TH - 1) / TH;
-                const long NT = (long)max_batch * tiles_y * tiles_x;
-                long G = std::min<long>(NT, std::max(1, 256 / gy));
-                if (G >= 8) G &= ~7L;
-                const long rounds = (NT + G - 1) / G;
-                const int simd_load = (ncomp + 3) / 4;
-                const double lds_reads = 1.0 / NREP + 0.2;
-                const double mfma_cyc = (double)c.nchunks * 45 * NREP * 16 * std::max(1.0, lds_reads / 0.5);
-                const double t_comp = rounds * (mfma_cyc * simd_load + 1100.0 * NREP) / 1.9e9;
-                const double bytes = (double)NT * ((double)gy * (2 * TH + 1) * 41 * r.c1 + (double)TH * 20 * r.c2) * esize;
-                const double t_mem = bytes / 5.0e12;
-                const double cost = std::max(t_comp, t_mem) + 0.15 * std::min(t_comp, t_mem) + 4e-6;
-                if (cost < best) {
-                    best = cost; found = true;
-                    c.TH = TH; c.TW = 20; c.WN = WN; c.NREP = NREP; c.pk = 4; c.pk_wgpc = 1;
+                for (int wstat = (wide && !no_wstat && c.nchunks > 2) ? 1 : 0; wstat >= 0; --wstat) {
+                    if (ncomp > 4 || !conv_pk2_fits(TH, WN, NREP, c.nchunks, wstat)) continue;
+                    const int tiles_y = (r.h_out + TH - 1) / TH;
+                    const long NT = (long)max_batch * tiles_y * tiles_x;
+                    long G = std::min<long>(NT, std::max(1, 256 / gy));
+                    if (G >= 8) G &= ~7L;
+                    const long rounds = (NT + G - 1) / G;
+                    const int simd_load = (ncomp + 3) / 4;
+                    const double lds_reads = (1.0 / NREP + 0.2) / mf;
+                    const double mfma_cyc = (double)c.nchunks * 45 * NREP * 16 * mf * std::max(1.0, lds_reads / 0.5);
+                    const double t_comp = rounds * (mfma_cyc * simd_load + 1100.0 * NREP) / 1.9e9;
+                    const double bytes = (double)NT * ((double)gy * (2 * TH + 1) * 41 * r.c1 + (double)TH * 20 * r.c2) * esize;
+                    const double t_mem = bytes / 5.0e12;
+                    double t_ing = 0.0;
+                    if (wide) {
+                        const double patch = (double)(2 * TH + 1) * 48 * 64 * c.nchunks, wbytes = (double)NTB * 9 * 1024 * c.nchunks;
+                        const bool resident = wstat || c.nchunks <= 2;
+                        t_ing = ((double)NT * gy * (patch + (resident ? 0.0 : wbytes)) + (resident ? (double)G * gy * wbytes : 0.0)) / 4.0e12;
+                    }
+                    const double cost = std::max(std::max(t_comp, t_mem), t_ing) + 0.15 * std::min(t_comp, t_mem) + 4e-6;
+                    if (cost < best) {
+                        best = cost; found = true;
+                        c.TH = TH; c.TW = 20; c.WN = WN; c.NREP = NREP; c.pk = 4; c.pk_wgpc = 1; c.pk_wstat = wstat;
+                    }
                 }
             }
         }
     }
     if (found) {
         c.ntiles_n = (c.ntiles_n + c.WN * c.NREP - 1) / (c.WN * c.NREP) * (c.WN * c.NREP);
-        c.pk_depth = conv_pk2_depth(c.TH, c.WN, c.NREP, c.nchunks);
-        c.lds = conv_pk2_lds_bytes(c.TH, c.WN, c.NREP, c.nchunks, c.pk_depth);
+        c.pk_depth = conv_pk2_depth(c.TH, c.WN, c.NREP, c.nchunks, c.pk_wstat);
+        c.lds = conv_pk2_lds_bytes(c.TH, c.WN, c.NREP, c.nchunks, c.pk_depth, c.pk_wstat);
     }
     return found;
 }
@@ -276,10 +306,11 @@ void choose_conv_cfg(int dtype, const ConvRow& r, bool conv0, int max_batch, Con
     c.nchunks = conv0 ? (32 / KC) : (r.c1 + KC - 1) / KC;
     c.pk = 0;
     if (allow_pk && !conv0 && (!ftw || ftw == 80) && (!fth || fth <= 4) && choose_pk1_cfg(f16 ? 2 : 4, r, max_batch, c, fth, fwn, fnrep)) return;
-    if (allow_pk && !conv0 && (!ftw || ftw == 20) && (!fth || fth % 4 == 0) && choose_pk_cfg(f16 ? 2 : 4, r, max_batch, c, fth, fwn, fnrep)) {
+    c.pk_wstat = 0;
+    if (allow_pk && !conv0 && (!ftw || ftw == 20) && (!fth || fth % 4 == 0) && choose_pk_cfg(dtype, r, max_batch, c, fth, fwn, fnrep)) {
         return;
     }
-    if (allow_pk && !conv0 && (!ftw || ftw == 20) && (!fth || fth % 4 == 0) && choose_pk2_cfg(f16 ? 2 : 4, r, max_batch, c, fth, fwn, fnrep)) return;
+    if (allow_pk && !conv0 && (!ftw || ftw == 20) && (!fth || fth % 4 == 0) && choose_pk2_cfg(dtype, r, max_batch, c, fth, fwn, fnrep)) return;
     const int ks = deconv ? 1 : r.k, st = deconv ? 1 : r.s;
     const int Ho = deconv ? r.h_in : r.h_out, Wo = deconv ? r.w_in : r.w_out;
     c.TH = c.TW = 0;

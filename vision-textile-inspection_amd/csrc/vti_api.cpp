@@ -57,8 +57,8 @@ static void report_stamps(const std::vector<unsigned long long>& h, size_t nwg, 
     if (pk) for (int i = 0; i < 16; ++i) names[i] = pkn[i];
     fprintf(stderr, "[stamps] %zu workgroups; median cycles since previous stamp (100 MHz s_memtime ticks x clock)\n", nwg);
     int prev = 0;
-    const int order[14] = {1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 14, 12};     // 13/14: inside the fused stage, before `end`
-    for (int oi = 0; oi < 14; ++oi) {
+    const int order[13] = {1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 12};     // 13: inside the fused stage, before `end` (14 / 15 hold s_memrealtime)
+    for (int oi = 0; oi < 13; ++oi) {
         const int i = order[oi];
         std::vector<long long> d;
         for (size_t w = 0; w < nwg; ++w) if (h[w * 16 + i] && h[w * 16 + prev]) d.push_back((long long)(h[w * 16 + i] - h[w * 16 + prev]));
@@ -71,6 +71,10 @@ static void report_stamps(const std::vector<unsigned long long>& h, size_t nwg, 
     for (size_t w = 0; w < nwg; ++w) tot.push_back((long long)(h[w * 16 + 12] - h[w * 16]));
     std::sort(tot.begin(), tot.end());
     fprintf(stderr, "[stamps] whole workgroup   median %8lld\n", tot[tot.size() / 2]);
+    std::vector<double> clk;            // in-kernel shader clock: s_memtime cycles per 100 MHz s_memrealtime tick
+    for (size_t w = 0; w < nwg; ++w)
+        if (h[w * 16 + 15] > h[w * 16 + 14]) clk.push_back((double)(h[w * 16 + 12] - h[w * 16]) / (double)(h[w * 16 + 15] - h[w * 16 + 14]) * 0.1);
+    if (!clk.empty()) { std::sort(clk.begin(), clk.end()); fprintf(stderr, "[stamps] in-kernel clock    median %.3f GHz (p10 %.3f, p90 %.3f)\n", clk[clk.size() / 2], clk[clk.size() / 10], clk[clk.size() * 9 / 10]); }
 }
 #endif
 
@@ -293,7 +297,7 @@ static void fill_conv_params(int conv_elem_size, ConvParams& p, const ConvRow& r
         p.pk = (ib < 0x80000000ull && ob < 0x80000000ull && rb < 0x80000000ull) ? g.pk : 0;   // 2^31 marks out-of-range lanes
         p.in_bytes = (unsigned)ib; p.out_bytes = (unsigned)ob; p.res_bytes = (unsigned)rb;
         p.pk_tiles = B * p.tiles_y * p.tiles_x;
-        p.pk_depth = g.pk_depth;
+        p.pk_depth = g.pk_depth; p.pk_wstat = g.pk_wstat;
         const int gy = g.ntiles_n / (g.WN * g.NREP);
         int G = std::min(p.pk_tiles, std::max(1, 256 * g.pk_wgpc / gy));
         if (const char* cap = getenv("VTI_PK_MAX_WGS")) G = std::max(1, std::min(G, atoi(cap)));   // tests: force many tiles per workgroup

@@ -163,15 +163,15 @@ size_t packed_l1pairs_bytes(int dtype);
 // conv_pk.hip: persistent 3x3/s1 kernel
 hipError_t launch_conv_pk(int dtype, int nrep, const ConvParams& p, size_t lds_bytes, hipStream_t st);
 size_t conv_pk_lds_bytes(int TH, int WN, int NREP, int nchunks);
-size_t conv_pk_lds_bytes(int TH, int WN, int NREP, int nchunks, int depth);
-int conv_pk_depth(int TH, int WN, int NREP, int nchunks);
+size_t conv_pk_lds_bytes(int TH, int WN, int NREP, int nchunks, int depth, int wstat = 0);   // wstat: all K chunks' weights resident in LDS
+int conv_pk_depth(int TH, int WN, int NREP, int nchunks, int wstat = 0);
 // stride-2 3x3 on the persistent schedule (ConvCfg.pk == 4)
 hipError_t launch_conv_pk2(int dtype, int nrep, const ConvParams& p, size_t lds_bytes, hipStream_t st);
-size_t conv_pk2_lds_bytes(int TH, int WN, int NREP, int nchunks, int depth);
-bool conv_pk2_fits(int TH, int WN, int NREP, int nchunks);
+size_t conv_pk2_lds_bytes(int TH, int WN, int NREP, int nchunks, int depth, int wstat = 0);
+bool conv_pk2_fits(int TH, int WN, int NREP, int nchunks, int wstat = 0);
 bool conv_pk2_instantiated(int nrep, int wn);
-int conv_pk2_depth(int TH, int WN, int NREP, int nchunks);
-bool conv_pk_fits(int TH, int WN, int NREP, int nchunks);
+int conv_pk2_depth(int TH, int WN, int NREP, int nchunks, int wstat = 0);
+bool conv_pk_fits(int TH, int WN, int NREP, int nchunks, int wstat = 0);
 bool conv_pk_instantiated(int nrep, int wn);
 hipError_t launch_conv1_pk(int dtype, int nrep, const ConvParams& p, size_t lds_bytes, hipStream_t st);
 size_t conv1_pk_lds_bytes(int nwm, int WN, int NREP, int nchunks, int depth, int wstat);

@@ -111,8 +111,12 @@ class Results:
 class YOLO:
     """`YOLO(path)` takes a VTIW1 container; `YOLO(None, scale=, nc=, seed=)` makes seeded random weights."""
 
-    def __init__(self, model=None, *, scale="n", nc=80, seed=1, cls_bias=None, dtype="fp16", device=0,
-                 names=None, mask_mode="logit", max_batch=64):
+    def __init__(self, model=None, *, scale="n", nc=80, seed=1, cls_bias=None, dtype="h2", device=0,
+                 names=None, mask_mode="logit", max_batch=64, drop_empty_masks=False):
+        """dtype: "h2" (default; split-fp16 storage on the fp16 matrix pipe -- results within the reference tolerance of the fp32 CPU
+        path: mask IoU >= 0.999, |d box| < 1e-3), "fp32" (exact-f32 MFMA, slower) or "fp16" (fastest; boxes drift ~1 px and masks to
+        IoU ~0.92-0.99 on untrained margins).  drop_empty_masks: newer Ultralytics releases drop instances whose thresholded mask is
+        empty (`keep = masks.sum((-2, -1)) > 0`); older ones (and the default here) return them."""
         self._blob = None
         if isinstance(model, (bytes, bytearray, memoryview)):
             self._blob = bytes(model)
@@ -130,7 +134,9 @@ class YOLO:
         self.scale, self.nc, self.dtype, self.device = scale, nc, dtype, device
         self._seed, self._cls_bias = seed, cls_bias
         self.mask_mode = mask_mode
+        self.drop_empty_masks = drop_empty_masks
         self.max_batch = max_batch
+        self._outs = {}
         self.names = names if names is not None else {i: f"class{i}" for i in range(nc)}
         self._engines = {}
 
@@ -174,18 +180,34 @@ class YOLO:
         H, W = letterbox_shape(H0, W0, imgsz)
         eng = self._engine(H, W, B, max_det)
         # the whole pipeline is enqueued without a host read in between (vti_predict: letterbox -> net -> NMS -> bit-packed
-        # masks for up to B * max_det instances -> scale_boxes); the counts are read once, at the end, to cut the Results
-        o = eng.alloc_outputs(B, max_det, B * max_det, "bits", frames.device)
+        # masks for up to B * max_det instances -> scale_boxes); the counts are read once, at the end, to cut the Results.
+        # The output set (~1 GB for 64 frames x 300 slots of 640x640 bit masks) is allocated once per (engine, B, max_det) and
+        # reused by later calls; what a Results object keeps are COPIES of its own rows (a few KB .. MB per frame).
+        key = (id(eng), B, max_det)
+        o = self._outs.get(key)
+        if o is None:
+            self._outs.clear()              # one cached set at a time: a new shape replaces the old one
+            o = self._outs[key] = eng.alloc_outputs(B, max_det, B * max_det, "bits", frames.device)
         eng.predict_into(frames, o, conf, iou, max_det, agnostic_nms, swap_rb, self.mask_mode, "bits")
         dets, xyxy, masks = o["dets"], o["xyxy"], o["masks"]
+        nonempty = None
+        if self.drop_empty_masks:           # m00 of every live slot straight from the bit-packed masks (vti_mask_stats_bits)
+            nonempty = eng.mask_stats_bits(masks, H, W, offsets=o["offsets"])[:, 0] > 0
         cnt = o["counts"].cpu().tolist()
         off = o["offsets"].cpu().tolist()
         out = []
         for b in range(B):
             n = cnt[b]
             data = torch.cat((xyxy[b, :n], dets[b, :n, 4:6]), 1)
-            m = Masks(masks[off[b]:off[b] + n], W, (H0, W0)) if n else None
-            r = Results((H0, W0), self.names, Boxes(data, (H0, W0)), m, dets[b, :n])
+            mb, db = masks[off[b]:off[b] + n], dets[b, :n]
+            if nonempty is not None and n:
+                keep = nonempty[off[b]:off[b] + n]
+                data, mb, db = data[keep], mb[keep], db[keep]
+                n = int(data.shape[0])
+            else:
+                mb, db = mb.clone(), db.clone()
+            m = Masks(mb, W, (H0, W0)) if n else None
+            r = Results((H0, W0), self.names, Boxes(data, (H0, W0)), m, db)
             r._engine = eng
             out.append(r)
         return out
