@@ -52,6 +52,10 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 MFMA_PEAK_TFLOPS = 2517.0      # dense fp16: 256 CU x 4 SIMD x 1024 FLOP/clk x 2.4 GHz (MI355X_MICROARCH.md: ~2.5 PF)
+# h2 (split-fp16): an algorithmic MAC needs at least three fp16 MFMA MACs (wh*xh, wh*xl, wl*xh), so the dense ceiling of the dtype is a
+# third of the fp16 pipe's (the figure round 2's review set for this scheme: 2,517 / 3 = 839 TF/s); this build issues four (two
+# MFMAs per 16 channels, the second half-filled).  Both fractions are reported: against 839 (`frac`) and against 2,517 (`frac_of_fp16_pipe`).
+H2_PEAK_TFLOPS = MFMA_PEAK_TFLOPS / 3.0
 F32_MFMA_PEAK_TFLOPS = 157.3   # f32-input MFMA (v_mfma_f32_16x16x4_f32): 64 FLOP/clk/SIMD = 1/16 of the fp16 rate (same guide)
 HBM_PEAK_GBS = 8000.0
 CONF, IOU, MAX_DET = 0.25, 0.7, 300      # Ultralytics predict() defaults
@@ -176,7 +180,7 @@ def other_engine_line(vti_amd, dtype, blob, frames, B, H, W, nc, cap, dev, n_par
     dt = time.perf_counter() - t0
     fwd_ms = float(np.mean([ev[2 * i].elapsed_time(ev[2 * i + 1]) for i in range(steps)]))
     ach = 2.0 * eng.macs_per_frame * B / (fwd_ms * 1e-3) / 1e12
-    peak = F32_MFMA_PEAK_TFLOPS if dtype == "fp32" else MFMA_PEAK_TFLOPS
+    peak = PEAKS[dtype]
     res = dict(dtype=DTYPE_TAG[dtype], value=round(B * steps / dt, 1), unit="frames/s", steps=steps, warmup=warmup, ms_per_step=round(dt / steps * 1e3, 4),
                roofline=dict(bound="mfma", achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 5), avg_ms=round(fwd_ms, 4)),
                note=DTYPE_NOTE[dtype])
@@ -220,6 +224,7 @@ def host_fed_line(vti_amd, eng, frames, B, H, W, cap, dev, steps, warmup):
 
 
 DTYPE_TAG = {"h2": "f16x2", "fp16": "f16", "fp32": "f32"}
+PEAKS = {"h2": round(H2_PEAK_TFLOPS, 1), "fp16": MFMA_PEAK_TFLOPS, "fp32": F32_MFMA_PEAK_TFLOPS}
 DTYPE_NOTE = {
     "h2": "split-fp16 storage: every weight and activation an fp16 (hi, lo) pair (22-23 significant bits), all products on the fp16 matrix "
           "pipe (v_mfma_f32_16x16x32_f16, two per 16 input channels), f32 accumulation",
@@ -506,7 +511,7 @@ def main():
     value = total_frames / elapsed
     flops_per_forward = 2.0 * eng.macs_per_frame * B
     achieved = flops_per_forward / (fwd_ms * 1e-3) / 1e12
-    peak = F32_MFMA_PEAK_TFLOPS if args.dtype == "fp32" else MFMA_PEAK_TFLOPS       # h2 and fp16 both run on the fp16 matrix pipe
+    peak = PEAKS[args.dtype]
 
     # HBM bytes per forward from the committed rocprofv3 PMC passes (tools/make_profiles.sh): only
     # valid for the configuration they were collected on.
@@ -532,8 +537,11 @@ def main():
                        "ranks": world, "backend": args.backend if world > 1 else None},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 5), "traffic": traffic,
-                         "mfma_issue_frac": round(achieved / peak * (4.0 if args.dtype == "h2" else 1.0), 5),
-                         "mfma_issue_note": "share of the matrix pipe's time the issued MFMAs occupy: h2 issues 4 fp16 MFMA MACs per algorithmic MAC (hi/lo x hi/lo; `achieved` and `frac` count ALGORITHMIC flops only)",
+                         "peak_note": ("f16x2 (split-fp16): 2517 / 3 -- an algorithmic MAC costs at least three fp16 MFMA MACs (wh*xh, wh*xl, wl*xh)"
+                                       if args.dtype == "h2" else "dense MFMA peak of the dtype (MI355X_MICROARCH.md)"),
+                         "frac_of_fp16_pipe": round(achieved / MFMA_PEAK_TFLOPS, 5) if args.dtype != "fp32" else None,
+                         "mfma_issue_frac": round(achieved / MFMA_PEAK_TFLOPS * (4.0 if args.dtype == "h2" else 1.0), 5) if args.dtype != "fp32" else None,
+                         "mfma_issue_note": "share of the fp16 matrix pipe's time the ISSUED MFMAs occupy (h2 issues 4 fp16 MFMA MACs per algorithmic MAC; `achieved` counts algorithmic flops only)",
                          "traffic_note": "HBM bytes per forward (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes, profiles/" + os.path.basename(tpath) + "); algorithmic unfused activation bytes = 91.6 MB/frame",
                          "kernel": f"vti conv family: conv3_pk / conv1_pk (persistent LDS-DMA 3x3 / 1x1) + conv_kernel (fused towers, stride 2) + stem_l1_kernel ({eng.num_launches} launches per forward incl. the SPPF pool; {len(eng.conv_table())} convs, {sum(1 for t in eng.conv_table() if t['fused'])} fused into their producer's kernel, decode fused into the box towers)",
                          "flop_per_launch": flops_per_forward, "avg_ms": round(fwd_ms, 4),

@@ -61,6 +61,45 @@ def test_config5_forward_layerwise_one_frame(m_engine):
     assert pe <= 1e-2 * max(oproto.abs().max().item(), 1.0), pe
 
 
+def test_config5_h2_engine_one_frame_and_batch_property():
+    """The same configuration on the h2 engine (the dtype that meets the north-star tolerance): one 1280x1280 frame through the
+    bs=16 plan against the plain fp32 oracle, layer by layer, at the h2 bound (4e-5 of the layer's max); and frames of a bs=16
+    batch are bit-identical to what the max_batch=2 plan computes for them."""
+    need_gpu()
+    import vti_amd
+    from oracle.model import OracleModel
+    eng = vti_amd.Engine("m", 80, H=S, W=S, max_batch=B5, dtype="h2")
+    blob = vti_amd.random_weights(eng, seed=1, gain=1.5)
+    eng.load_weights(blob, 0)
+    base = frames_u8(2, S, S, seed=41)
+    fr = np.concatenate([base] * 8, 0)
+    pred, proto = eng.forward(torch.from_numpy(fr).cuda(), swap_rb=True)
+    torch.cuda.synchronize()
+    assert torch.isfinite(pred).all() and torch.isfinite(proto).all() and proto.dtype == torch.float32
+    for r in range(1, 8):
+        assert torch.equal(pred[:2], pred[2 * r:2 * r + 2]) and torch.equal(proto[:2], proto[2 * r:2 * r + 2])
+    om = OracleModel(blob, S, S, mode="fp32")
+    opred, oproto = om.forward_u8(base[:1], swap_rb=True, record=True)
+    checked = 0
+    for i, t in enumerate(eng.conv_table()):
+        try:
+            got = eng.debug_conv_output(i, 1).cpu()
+        except vti_amd.VtiError:
+            continue
+        ref = om.taps[t["name"]]
+        err = (got - ref).abs().max().item()
+        assert err <= 4e-5 * max(ref.abs().max().item(), 1.0), f"{t['name']}: max|d|={err:.3e} ref max={ref.abs().max():.3e}"
+        checked += 1
+    assert checked >= 60
+    pe = (proto[:1].cpu().permute(0, 3, 1, 2) - oproto).abs().max().item()
+    assert pe <= 4e-5 * max(oproto.abs().max().item(), 1.0), pe
+    small = vti_amd.Engine("m", 80, H=S, W=S, max_batch=2, dtype="h2")
+    small.load_weights(blob, 0)
+    p2, q2 = small.forward(torch.from_numpy(base).cuda(), swap_rb=True)
+    torch.cuda.synchronize()
+    assert torch.equal(p2, pred[:2]) and torch.equal(q2, proto[:2])
+
+
 def test_config5_batch16_properties(m_engine):
     """bs=16: 4 distinct frames x 4 copies in a shuffled order -> copies bit-identical; and bit-identical to what a
     max_batch=2 engine (different tile plans) computes for the same frames."""

@@ -5,7 +5,8 @@ Tolerances (north_star: mask IoU >= 0.999, |d box| < 1e-3):
       boxes < 1e-3 NORMALISED (|d|/max(H,W)) and < 5e-3 letterboxed px -- the px figure is the fp32
       accumulation-order floor at stride 32, shown by the fp64 cross-check below.
   fp16 engine vs fp16-emulating oracle (rounds where the engine rounds): every conv output within
-      1e-2 relative (a few fp16 ulps of drift over 76 layers); scores 2e-2."""
+      6e-3 relative (measured 2.8e-3: a few fp16 ulps of drift over 76 layers); scores 2e-2.
+  h2 engine (split-fp16 pairs) vs the fp32 oracle: every conv output within 4e-5 relative (measured 7e-6), boxes < 2e-2 px."""
 import numpy as np
 import pytest
 import torch
@@ -17,9 +18,9 @@ pytestmark = pytest.mark.gpu
 CONFIGS = [
     # scale, nc, H, W, B, dtype, per-layer rel tol
     ("n", 80, 640, 640, 1, "fp32", 2e-5),      # BASELINE config geometry, exact-f32 MFMA
-    ("n", 80, 640, 640, 2, "fp16", 1e-2),      # BASELINE config (fp16)
-    ("n", 2, 736, 960, 1, "fp16", 1e-2),       # the reference's real input: ragged 92x120 / 46x60 / 23x30 maps
-    ("m", 80, 320, 320, 1, "fp16", 1e-2),      # m-scale channel counts (48..576), 96 convs
+    ("n", 80, 640, 640, 2, "fp16", 6e-3),      # BASELINE config (fp16); measured 2.8e-3 of the layer's max
+    ("n", 2, 736, 960, 1, "fp16", 6e-3),       # the reference's real input: ragged 92x120 / 46x60 / 23x30 maps
+    ("m", 80, 320, 320, 1, "fp16", 6e-3),      # m-scale channel counts (48..576), 96 convs
     ("s", 80, 256, 256, 2, "fp32", 2e-5),
     # h2 (split-fp16 pairs, ~22 significant bits, hardware-rate SiLU) against the plain fp32 oracle
     ("n", 80, 640, 640, 2, "h2", 4e-5),
@@ -116,16 +117,27 @@ def test_batch_invariance_and_flags():
     oa, _ = om.forward_u8(fr, swap_rb=False)
     assert (pa[:, 4:84].cpu() - oa[:, 4:84]).abs().max() < 2e-2
     assert not torch.allclose(pa[:, 4:84], p2[:, 4:84], atol=1e-3)         # and the flag does something
+    # the same invariance on the h2 engine (22-bit storage), where "close" is tight enough to pin the stem's two banded weight
+    # packings (pack_stem_toeplitz: both channel orders) against each other AND against the oracle run with the same flag:
+    # a misplaced tap or channel costs far more than 2e-2 px / 1e-4 in the scores
+    eng2, om2, _ = engine_and_oracle("n", 80, 640, 640, 2, "h2")
+    ha, qa = eng2.forward(x, swap_rb=False)
+    hb, qb = eng2.forward(x.flip(-1).contiguous(), swap_rb=True)
+    assert (ha[:, 4:84] - hb[:, 4:84]).abs().max() < 1e-4 and (ha[:, :4] - hb[:, :4]).abs().max() < 2e-2 and (qa - qb).abs().max() < 1e-3
+    oa2, op2 = om2.forward_u8(fr, swap_rb=False)
+    assert (ha[:, 4:84].cpu() - oa2[:, 4:84]).abs().max() < 1e-4 and (ha[:, :4].cpu() - oa2[:, :4]).abs().max() < 2e-2
+    assert (qa.cpu().permute(0, 3, 1, 2) - op2).abs().max() < 1e-3
 
 
-def test_full_size_batch_properties():
-    """BASELINE config size (bs=64, 640x640, fp16): checked through size-independent properties --
+@pytest.mark.parametrize("dtype", ["h2", "fp16"])
+def test_full_size_batch_properties(dtype):
+    """BASELINE config size (bs=64, 640x640; the benchmarked h2 engine and the fp16 engine): checked through size-independent properties --
     duplicated frames give bit-identical outputs wherever they sit in the batch, and the first frames
     still match the oracle."""
     need_gpu()
     import vti_amd
     B = 64
-    eng = vti_amd.Engine("n", 80, H=640, W=640, max_batch=B, dtype="fp16")
+    eng = vti_amd.Engine("n", 80, H=640, W=640, max_batch=B, dtype=dtype)
     blob = vti_amd.random_weights(eng, seed=1)
     eng.load_weights(blob, 0)
     base = frames_u8(8, 640, 640, seed=9)
@@ -138,21 +150,24 @@ def test_full_size_batch_properties():
     for r in range(1, 8):
         assert torch.equal(pred[:8], pred[8 * r:8 * r + 8]) and torch.equal(proto[:8], proto[8 * r:8 * r + 8])
     from oracle.model import OracleModel
-    opred, _ = OracleModel(blob, 640, 640, "fp16").forward_u8(base[:2])
-    assert (pred[:2, 4:84].cpu() - opred[:, 4:84]).abs().max() < 2e-2
+    opred, _ = OracleModel(blob, 640, 640, "fp32" if dtype == "h2" else "fp16").forward_u8(base[:2])
+    assert (pred[:2, 4:84].cpu() - opred[:, 4:84]).abs().max() < (1e-4 if dtype == "h2" else 2e-2)
+    if dtype == "h2":
+        assert (pred[:2, :4].cpu() - opred[:, :4]).abs().max() < 2e-2
 
 
-def test_batch_and_geometry_invariance_at_full_size():
+@pytest.mark.parametrize("dtype", ["h2", "fp16"])
+def test_batch_and_geometry_invariance_at_full_size(dtype):
     """BASELINE size (64 frames of 640x640): every frame's pred/proto must be BIT-identical to what the same engine code
     produces for that frame in a 3-frame batch -- the plans differ (tile shapes, persistent tile chains, workgroups per
     layer are chosen per max_batch), the arithmetic per output element must not.  Size-independent property: no oracle."""
     need_gpu()
     import vti_amd
     fr = frames_u8(64, 640, 640, seed=11)
-    big = vti_amd.Engine("n", 80, H=640, W=640, max_batch=64, dtype="fp16")
+    big = vti_amd.Engine("n", 80, H=640, W=640, max_batch=64, dtype=dtype)
     blob = vti_amd.random_weights(big, 1, cls_bias=-6.0)
     big.load_weights(blob, 0)
-    small = vti_amd.Engine("n", 80, H=640, W=640, max_batch=3, dtype="fp16")
+    small = vti_amd.Engine("n", 80, H=640, W=640, max_batch=3, dtype=dtype)
     small.load_weights(blob, 0)
     x = torch.from_numpy(fr).cuda()
     pred, proto = big.forward(x, swap_rb=True)

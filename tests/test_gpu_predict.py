@@ -84,8 +84,10 @@ def test_fp16_engine_drift_against_the_fp32_oracle():
     """The BENCHMARKED dtype against the fp32 CPU oracle, end to end (boxes AND masks), with the tolerance it actually meets written
     down.  north_star asks IoU >= 0.999 / |d box| < 1e-3: the fp32 engine meets that (test above and bench.py's fp32_engine line);
     fp16 storage of weights and of 76 layers of activations drifts by a few fp16 ulps per layer, which on these seeded random nets
-    (no trained margin between classes) means: boxes within 4 px (0.6 % of the 640-px frame; measured 1.4-1.9), >= 95 % of the
-    oracle's instances kept with the same class, mean mask IoU >= 0.98 over the matched ones (measured 0.995), worst one >= 0.8."""
+    (no trained margin between classes) means (bounds = about twice what is measured): boxes within 2.8 px (measured 1.0-1.4),
+    >= 97 % of the oracle's instances kept with the same class, |d conf| < 2e-2 (measured 7-9e-3), mean mask IoU >= 0.99 over the
+    matched ones (measured 0.995-0.997), worst one >= 0.82 (measured 0.91-0.93).  That is NOT the north-star gate -- the h2 engine
+    (test below) and the fp32 engine meet it; plain fp16 is kept as the fastest, stated-drift option."""
     need_gpu()
     import vti_amd
     from oracle import parity as op
@@ -96,9 +98,9 @@ def test_fp16_engine_drift_against_the_fp32_oracle():
     want = op.oracle_predict(model._blob, fr, 80, 0.25, 0.7, 300, mode="fp32")
     res = op.compare(got, want, 640, 640)
     assert res["n_instances"] >= 20, res
-    assert res["n_matched"] >= 0.95 * res["n_instances"] and abs(res["n_engine"] - res["n_instances"]) <= 0.1 * res["n_instances"], res
-    assert res["box_px_max"] < 4.0 and res["conf_abs_max"] < 3e-2, res
-    assert res["mask_iou_mean"] >= 0.98 and res["mask_iou_min"] >= 0.8, res
+    assert res["n_matched"] >= 0.97 * res["n_instances"] and abs(res["n_engine"] - res["n_instances"]) <= 0.05 * res["n_instances"], res
+    assert res["box_px_max"] < 2.8 and res["conf_abs_max"] < 2e-2, res
+    assert res["mask_iou_mean"] >= 0.99 and res["mask_iou_min"] >= 0.82, res
     # ... and the same pipeline on the exact-f32 engine meets the north-star gate itself
     m32 = vti_amd.YOLO(model._blob, dtype="fp32", max_batch=2)
     got32 = op.engine_predict(m32._engine(640, 640, 2), torch.from_numpy(fr).cuda(), 0.25, 0.7, 300)
@@ -164,7 +166,7 @@ def test_drop_empty_masks_flag_and_output_reuse():
     n_empty = 0
     for r, (bx, mk), d in zip(plain, snap, drop):
         assert torch.equal(r.boxes.data, bx) and torch.equal(r.masks.data_u8, mk)          # earlier Results are copies
-        keep = mk.flatten(1).any(1)
+        keep = mk.flatten(1).any(1).bool()
         n_empty += int((~keep).sum())
         assert len(d.boxes) == int(keep.sum())
         assert torch.equal(d.boxes.data, bx[keep]) and torch.equal(d.masks.data_u8, mk[keep])

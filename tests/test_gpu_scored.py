@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("dtype,nc", [("fp16", 80), ("fp32", 80), ("fp16", 2)])
+@pytest.mark.parametrize("dtype,nc", [("h2", 80), ("fp16", 80), ("fp32", 80), ("fp16", 2), ("h2", 2)])
 def test_pairs_and_detections_match_the_unscored_path(dtype, nc):
     need_gpu()
     import vti_amd
