@@ -5,23 +5,24 @@
 #   3. single-stream per-launch roofline table                  -> <tag>_op_roofline.txt   (tools/op_times.py)
 #   4. --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES (own pass) -> <tag>_mfma_busy.txt: matrix-pipe busy share per conv kernel
 # The program is always directly after `--` (no env/bash hop under rocprofv3).
-tag=${1:-r02}
+tag=${1:-r03}
+DT=${2:-h2}                 # engine dtype of the profiled run (the bench headline's)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/profiles; mkdir -p $out; rm -rf gpurun_out/_p1 gpurun_out/_p2 gpurun_out/_p3 gpurun_out/_p4 gpurun_out/_ops
-args="bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-fp32-line --parity-frames 0 --preheat 0.2"
+args="bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-fp32-line --no-fp16-line --no-host-fed --parity-frames 0 --preheat 0.2 --dtype $DT"
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/_p1 -- python3 $args > $out/${tag}_bench_under_rocprof.json 2> gpurun_out/_p1.err || exit 1
 cp $(find gpurun_out/_p1 -name '*kernel_stats.csv' | head -1) $out/${tag}_bench_kernel_stats.csv
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/_p2 -- python3 $args > /dev/null 2> gpurun_out/_p2.err || exit 1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/_p3 -- python3 $args > /dev/null 2> gpurun_out/_p3.err || exit 1
 export VTI_SINGLE_STREAM=1
 mkdir -p gpurun_out/_ops
-VTI_LIST_OPS=1 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/_ops -- python3 tools/prof_forward.py 64 fp16 5 2> gpurun_out/_ops/ops.txt > /dev/null || exit 1
-python3 tools/op_times.py gpurun_out/_ops 64 fp16 > $out/${tag}_op_roofline.txt || exit 1
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d gpurun_out/_p4 -- python3 tools/prof_forward.py 64 fp16 3 > /dev/null 2> gpurun_out/_p4.err || exit 1
+VTI_LIST_OPS=1 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/_ops -- python3 tools/prof_forward.py 64 $DT 5 2> gpurun_out/_ops/ops.txt > /dev/null || exit 1
+python3 tools/op_times.py gpurun_out/_ops 64 $DT > $out/${tag}_op_roofline.txt || exit 1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d gpurun_out/_p4 -- python3 tools/prof_forward.py 64 $DT 3 > /dev/null 2> gpurun_out/_p4.err || exit 1
 unset VTI_SINGLE_STREAM
-python3 - "$tag" <<'PY'
+python3 - "$tag" "$DT" <<'PY'
 import csv, glob, collections, json, re, sys
-tag = sys.argv[1]
+tag, DT = sys.argv[1], sys.argv[2]
 out = "gpurun_out/profiles"
 def fam(n):
     if any(k in n for k in ("conv_kernel", "stem_kernel", "conv3_pk", "conv1_pk", "stem_l1", "bneck_pk", "convfold_kernel")):
@@ -31,9 +32,11 @@ def fam(n):
         if k in n: return k
     return None
 def short(n):
-    m = re.search(r"vti\d*(\w+?)I(DF16_|f)((?:L[ib]\d+E)*)", n)
-    if not m: return n[:40]
-    return m.group(1) + "<" + ("h" if m.group(2) != "f" else "f") + "," + ",".join(re.findall(r"L[ib](\d+)E", m.group(3))) + ">"
+    m = re.search(r"vti\d*(\w+?)I(DF16_|f|NS_4h2_tE)((?:L[ib]\d+E)*)", n)          # mangled names
+    if m: return m.group(1) + "<" + {"DF16_": "h", "f": "f"}.get(m.group(2), "h2") + "," + ",".join(re.findall(r"L[ib](\d+)E", m.group(3))) + ">"
+    m = re.search(r"vti::(\w+)<(?:vti::)?(\w+)((?:, [\w]+)*)>", n)                   # demangled names
+    if m: return m.group(1) + "<" + {"_Float16": "h", "float": "f", "h2_t": "h2"}.get(m.group(2), m.group(2)) + m.group(3).replace(" ", "") + ">"
+    return n[:40]
 # ---- kernel trace: per-family totals over the run
 f = glob.glob("gpurun_out/_p1/**/*kernel_trace.csv", recursive=True)[0]
 agg = collections.defaultdict(list)
@@ -41,7 +44,7 @@ for r in csv.DictReader(open(f)):
     k = fam(r["Kernel_Name"])
     if k: agg[k].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 nfwd = len(agg["sppf_pool"])                # one SPPF pool launch per forward
-lines = [f"rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline ...   ({nfwd} forwards incl. calibration/pre-heat/warm-up/isolated timing)",
+lines = [f"rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline ... --dtype {DT}   ({nfwd} forwards incl. calibration/pre-heat/warm-up/isolated timing)",
          "NOTE: the forward runs its independent branches on side streams, so kernels overlap: per-kernel durations here are",
          "inflated by sharing the chip and their sum exceeds the wall time of a forward (bench.py reports that).",
          f"Non-overlapped per-launch durations with work and roofline fractions: {tag}_op_roofline.txt (VTI_SINGLE_STREAM=1).",
@@ -66,7 +69,7 @@ ft, fc = pmc_sum("gpurun_out/_p2", "FETCH_SIZE")
 wt, wc = pmc_sum("gpurun_out/_p3", "WRITE_SIZE")
 nf = fc["sppf_pool"]; nw = wc["sppf_pool"]
 npf = max(fc["nms_kernel"], 1); npw = max(wc["nms_kernel"], 1)
-res = {"note": "HBM traffic per forward (conv family, sppf_pool) / per bench step (post-processing kernels), bs=64, from rocprofv3 PMC, separate passes; FETCH_SIZE x2 correction for gfx950 applied",
+res = {"dtype": DT, "note": "HBM traffic per forward (conv family, sppf_pool) / per bench step (post-processing kernels), bs=64, from rocprofv3 PMC, separate passes; FETCH_SIZE x2 correction for gfx950 applied",
        "families": {}}
 for k in ft:
     fwdk = k.startswith("conv family") or k in ("sppf_pool", "upsample2x", "decode_kernel")
@@ -80,7 +83,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(float))
 for r in csv.DictReader(open(f)):
     if fam(r["Kernel_Name"]) and fam(r["Kernel_Name"]).startswith("conv family"):
         acc[short(r["Kernel_Name"])][r["Counter_Name"]] += float(r["Counter_Value"])
-L = ["rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES -- python3 tools/prof_forward.py 64 fp16 3   (VTI_SINGLE_STREAM=1; sums over all launches of a kernel instantiation)",
+L = ["rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES -- python3 tools/prof_forward.py 64 " + DT + " 3   (VTI_SINGLE_STREAM=1; sums over all launches of a kernel instantiation)",
      "SQ_VALU_MFMA_BUSY_CYCLES is summed over the 1024 SIMDs, SQ_BUSY_CYCLES over the 32 shader engines (32 SIMDs each), so",
      "matrix-pipe busy share per SIMD = MFMA_BUSY / (32 x SQ_BUSY)  [last column]",
      f"{'kernel<dtype,template args>':44s} {'MFMA_BUSY':>14s} {'SQ_BUSY':>14s} {'ratio':>8s} {'busy/SIMD':>10s}"]

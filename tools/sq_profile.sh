@@ -15,6 +15,8 @@ tag = sys.argv[1]
 def short(n):
     m = re.search(r"vti\d*(\w+?)I(DF16_|f|NS_4h2_tE)((?:L[ib]\d+E)*)", n)
     if m: return m.group(1) + "<" + {"DF16_": "h", "f": "f"}.get(m.group(2), "h2") + "," + ",".join(re.findall(r"L[ib](\d+)E", m.group(3))) + ">"
+    m = re.search(r"vti::(\w+)<(?:vti::)?(\w+)((?:, [\w]+)*)>", n)                   # demangled names
+    if m: return m.group(1) + "<" + {"_Float16": "h", "float": "f", "h2_t": "h2"}.get(m.group(2), m.group(2)) + m.group(3).replace(" ", "") + ">"
     m = re.search(r"vti::(\w+)", n)
     return m.group(1) if m else n[:40]
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()

@@ -541,22 +541,30 @@ constexpr int sl_pitch(int es) { return es == 2 ? 520 : 512; }
 constexpr int SL_NJ = (SL_SW + 3) / 4, SL_NWIN = SL_SH * SL_NJ;       // 4-pixel windows per stem row / per tile
 static_assert(24 * (SL_NJ - 1) + 32 <= 512 && SL_RWD * 4 <= 512, "stem windows must stay inside a patch row");
 
+// h2: the u8 patch is staged as plain fp16 INTEGERS (0..255 are exact; the 1/255 lives in the stem's weights, which carry the hi/lo
+// split alone: two K = 32 MFMAs per window and input row, no lo plane of x, half the patch bytes) -- see phase 2.
 size_t stem_l1_lds_bytes(int dtype) {
-    const size_t es = dtype == VTI_F16 ? 2 : 4;
-    return (((size_t)SL_RH * sl_pitch((int)es) * es + 15) & ~(size_t)15) + (size_t)SL_NSP * 16 * es;
+    const size_t es = dtype == VTI_F16 ? 2 : 4, pes = dtype == VTI_F32 ? 4 : 2;
+    return (((size_t)SL_RH * sl_pitch((int)pes) * pes + 15) & ~(size_t)15) + (size_t)SL_NSP * 16 * es;
 }
 
 template <typename T>
 __global__ __launch_bounds__(256) void stem_l1_kernel(const ConvParams p) {
     using vec = typename Tr<T>::vec;
-    constexpr int VEC = Tr<T>::VEC, KC = Tr<T>::KC, ES = (int)sizeof(T);
+    constexpr int ES = (int)sizeof(T);
+    // the patch's element type: T, except h2 -> plain fp16 holding the bytes' integer values (the stem's weights are w / 255 as hi / lo planes)
+    constexpr bool XH = Tr<T>::H2;
+    using PT = typename std::conditional<XH, half_t, T>::type;
+    using pvec = typename Tr<PT>::vec;
+    constexpr int VEC = Tr<PT>::VEC, KC = Tr<PT>::KC, PES = (int)sizeof(PT);
     constexpr int NCH = 32 / KC;                        // stem K chunks (27 -> 32)
+    constexpr int NWP = XH ? 2 : 1;                     // weight planes per (window pixel, row, chunk): h2 = hi, lo
     constexpr int NS1 = sizeof(T) == 2 ? 5 : 9;         // layer-1 K steps
     constexpr bool FAST = !Tr<T>::F32;
-    constexpr int SL_PITCH = sl_pitch(ES);
-    constexpr int CP_BYTES = (SL_RH * SL_PITCH * ES + 15) & ~15;
+    constexpr int SL_PITCH = sl_pitch(PES);
+    constexpr int CP_BYTES = (SL_RH * SL_PITCH * PES + 15) & ~15;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    T* cp = (T*)smem;                                   // the input patch, already v/255 in T: [row][SL_PITCH]
+    PT* cp = (PT*)smem;                                 // the input patch, already v/255 in T (h2: the integer v in fp16): [row][SL_PITCH]
     char* sout = smem + CP_BYTES;                       // [stem pixel][16 ch] of T
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
@@ -575,15 +583,15 @@ __global__ __launch_bounds__(256) void stem_l1_kernel(const ConvParams p) {
     // Every weight fragment of the three convs is fetched NOW (fp16: 48 + 40 + 8 registers), so that the round trips hide under the
     // patch staging: loaded where they are used, each phase opened with an exposed L2 latency (the stem phase alone spent ~6 k of
     // its 12 k cycles per workgroup waiting for its 12 fragments).
-    vec wA[4][3][NCH];
+    pvec wA[4][3][NCH * NWP];
     {
-        const vec* w0 = (const vec*)p.w0 + (size_t)(p.swap_rb ? 1 : 0) * (4 * 3 * NCH * 64);
+        const pvec* w0 = (const pvec*)p.w0 + (size_t)(p.swap_rb ? 1 : 0) * (4 * 3 * NCH * NWP * 64);
 #pragma unroll
         for (int pp = 0; pp < 4; ++pp)
 #pragma unroll
             for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-                for (int c = 0; c < NCH; ++c) wA[pp][kh][c] = w0[(size_t)((pp * 3 + kh) * NCH + c) * 64 + lane];
+                for (int c = 0; c < NCH * NWP; ++c) wA[pp][kh][c] = w0[(size_t)((pp * 3 + kh) * NCH * NWP + c) * 64 + lane];
     }
     vec w1all[NS1][2];
 #pragma unroll
@@ -657,8 +665,13 @@ __global__ __launch_bounds__(256) void stem_l1_kernel(const ConvParams p) {
                 const int rd = lane + 64 * ch;
                 if (ry >= SL_RH || rd >= SL_RWD) continue;
                 const unsigned v = vv[it][ch];
-                T* o = cp + (size_t)ry * SL_PITCH + 4 * rd;
-                if constexpr (sizeof(T) == 2) {
+                PT* o = cp + (size_t)ry * SL_PITCH + 4 * rd;
+                if constexpr (XH) {
+                    half4 hv;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) hv[k] = (half_t)(float)((v >> (8 * k)) & 0xffu);      // exact
+                    *(half4*)o = hv;
+                } else if constexpr (sizeof(T) == 2) {
                     half4 hv;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) hv[k] = (half_t)((float)((v >> (8 * k)) & 0xffu) * (1.0f / 255.0f));
@@ -673,8 +686,8 @@ __global__ __launch_bounds__(256) void stem_l1_kernel(const ConvParams p) {
     // elements [4 SL_RWD, SL_PITCH) of every row: read by the last stem window of the row, must be finite (zero weights meet them)
     for (int i = tid; i < SL_RH * ((SL_PITCH - 4 * SL_RWD) / 4); i += 256) {
         const int ry = i / ((SL_PITCH - 4 * SL_RWD) / 4), c4 = i - ry * ((SL_PITCH - 4 * SL_RWD) / 4);
-        T* o = cp + (size_t)ry * SL_PITCH + 4 * SL_RWD + 4 * c4;
-        o[0] = to_T<T>(0.f); o[1] = to_T<T>(0.f); o[2] = to_T<T>(0.f); o[3] = to_T<T>(0.f);
+        PT* o = cp + (size_t)ry * SL_PITCH + 4 * SL_RWD + 4 * c4;
+        o[0] = to_T<PT>(0.f); o[1] = to_T<PT>(0.f); o[2] = to_T<PT>(0.f); o[3] = to_T<PT>(0.f);
     }
     __syncthreads();
     VTI_STAMP(1);
@@ -695,12 +708,12 @@ __global__ __launch_bounds__(256) void stem_l1_kernel(const ConvParams p) {
             // rows fastest: the 16 windows of a block are 16 different stem rows, whose output pixels sy * 81 + 4 J + p fall on 4
             // different bank groups of the [pixel][32 B] tile (consecutive J of one row would all hit the same one: 16-way conflict)
             const int J = wc / SL_SH, sy = wc - J * SL_SH;
-            const T* base = cp + (size_t)(2 * sy) * SL_PITCH + 24 * J + g * VEC;
-            vec x[3][NCH];
+            const PT* base = cp + (size_t)(2 * sy) * SL_PITCH + 24 * J + g * VEC;
+            pvec x[3][NCH];
 #pragma unroll
             for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-                for (int c = 0; c < NCH; ++c) x[kh][c] = *(const vec*)(base + kh * SL_PITCH + c * KC);
+                for (int c = 0; c < NCH; ++c) x[kh][c] = *(const pvec*)(base + kh * SL_PITCH + c * KC);
             f32x4 acc[4];
 #pragma unroll
             for (int pp = 0; pp < 4; ++pp) {
@@ -708,7 +721,9 @@ __global__ __launch_bounds__(256) void stem_l1_kernel(const ConvParams p) {
 #pragma unroll
                 for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-                    for (int c = 0; c < NCH; ++c) acc[pp] = mma(wA[pp][kh][c], x[kh][c], acc[pp]);
+                    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+                        for (int wp = 0; wp < NWP; ++wp) acc[pp] = mma(wA[pp][kh][c * NWP + wp], x[kh][c], acc[pp]);   // h2: (wh + wl) . v
             }
             const bool row_in = (unsigned)(sy0 + sy) < (unsigned)Hs;
 #pragma unroll

@@ -102,11 +102,11 @@ struct Builder {
 //    waves that share the busiest SIMD, times the rounds of tiles per workgroup slot, at ~1.9 GHz;
 //  * LDS operand reads per MFMA (1/NREP + 1/5) stretch the MFMA phase once they pass ~0.5.
 // 4-byte storage (fp32 / h2): K chunks are 16 channels, so a layer has twice the chunks and twice the weight bytes of the fp16 engine and
-// its weights rarely fit beside the patches; streamed with every patch they are 60-70 % of a step's LDS-DMA bytes, and the L2 -> LDS ingest
-// (~4 TB/s over the chip, measured: every geometry of a 64 -> 64 layer at 40x40 takes the same 34 us) is what bounds these layers.  For
-// them the search also tries `wstat`: ALL chunks of a workgroup's n-group resident (which favours splitting N across workgroups: a
-// 2-tile slice of a 64 -> 64 layer is 72 KB), and prices the ingest: patches once per n-group + weights per tile (streamed) or per
-// workgroup (resident).
+// its weights rarely fit beside the patches; streamed with every patch they are 60-70 % of a step's LDS-DMA bytes.  The search therefore
+// also tries `wstat` -- ALL chunks of a workgroup's n-group resident (which favours splitting N across workgroups: a 2-tile slice of a
+// 64 -> 64 layer is 72 KB) -- and prices the L2 -> LDS ingest (patches once per n-group + weights per tile, streamed, or per workgroup,
+// resident) at 8 TB/s: measured, 173 MB of ingest pass in 30 us, so it seldom binds; what does decide these layers is whether TWO
+// workgroups fit a CU (`solo` below).
 static bool choose_pk_cfg(int dtype, const ConvRow& r, int max_batch, ConvCfg& c, int fth, int fwn, int fnrep) {
     const char* no = getenv("VTI_NO_PK");
     if (no && no[0] == '1') return false;
@@ -123,6 +123,7 @@ static bool choose_pk_cfg(int dtype, const ConvRow& r, int max_batch, ConvCfg& c
         for (int NREP = 1; NREP <= 5; ++NREP) {
             if (fnrep && NREP != fnrep) continue;
             if (!conv_pk_instantiated(NREP, WN)) continue;
+            if (dtype == VTI_H2 && NREP == 5 && !fnrep) continue;       // h2 at NREP = 5 spills (two prepared operand sets beside 100 accumulators)
             const int NTB = WN * NREP;
             const int gy = (c.ntiles_n + NTB - 1) / NTB;
             const double n_eff = (double)c.ntiles_n / (gy * NTB);
@@ -143,7 +144,12 @@ static bool choose_pk_cfg(int dtype, const ConvRow& r, int max_batch, ConvCfg& c
                     const double lds_reads = (1.0 / NREP + 0.2) / mf;
                     // NREP = 5 keeps 100 accumulator registers and a shallow operand queue: measured 12 % behind two n-groups of 3
                     // (tools/pk_sweep.py: 64 -> 80 at 80 x 80: 61 vs 54 us), hence the factor (fitted so that the model flips where the sweep does)
-                    const double mfma_cyc = (double)c.nchunks * 45 * NREP * 16 * mf * std::max(1.0, lds_reads / 0.5) * (NREP == 5 ? 1.6 : 1.0);
+                    // 4-byte storage: a lone compute wave keeps its SIMD's matrix pipe ~70 % busy inside the MFMA phase (operand preparation,
+                    // LDS reads and waits issue in order with the MFMAs: stamps), a second resident workgroup fills those slots -- measured
+                    // (tools/pk_sweep.py h2): 8 x 20 tiles with 66 KB of LDS, i.e. two workgroups per CU, beat every 1-per-CU geometry by
+                    // 1.25-1.5x on the 32- and 64-output-channel layers
+                    const double solo = wide ? ((ncomp * wgpc > 4) ? 1.1 : 1.45) : 1.0;
+                    const double mfma_cyc = (double)c.nchunks * 45 * NREP * 16 * mf * solo * std::max(1.0, lds_reads / 0.5) * (NREP == 5 ? 1.6 : 1.0);
                     const double t_comp = rounds * (mfma_cyc * simd_load + 1100.0 * NREP) / 1.9e9;   // a SIMD partner's MFMAs hide the epilogue
                     const double bytes = (double)NT * ((double)gy * (TH + 2) * 22 * r.c1 + (double)TH * 20 * r.c2) * esize;
                     const double t_mem = bytes / 5.0e12;
@@ -151,9 +157,11 @@ static bool choose_pk_cfg(int dtype, const ConvRow& r, int max_batch, ConvCfg& c
                     if (wide) {
                         const double patch = (double)(TH + 2) * 24 * 64 * c.nchunks, wbytes = (double)NTB * 9 * 1024 * c.nchunks;
                         const bool resident = wstat || c.nchunks <= 2;
-                        t_ing = ((double)NT * gy * (patch + (resident ? 0.0 : wbytes)) + (resident ? (double)G * gy * wbytes : 0.0)) / 4.0e12;
+                        t_ing = ((double)NT * gy * (patch + (resident ? 0.0 : wbytes)) + (resident ? (double)G * gy * wbytes : 0.0)) / 8.0e12;
                     }
-                    const double cost = std::max(std::max(t_comp, t_mem), t_ing) + 0.15 * std::min(t_comp, t_mem) + 4e-6;
+                    // every further n-group walks the whole K range again for its 16 NTB channels (patch DMA, pixel-operand reads, barriers): measured
+                    // on 256 -> 80 at 20x20, five 1-tile groups 61 us against 50 us for two groups of three
+                    const double cost = (std::max(std::max(t_comp, t_mem), t_ing) + 0.15 * std::min(t_comp, t_mem)) * (wide ? 1.0 + 0.06 * (gy - 1) : 1.0) + 4e-6;
                     if (cost < best) {
                         best = cost; found = true;
                         c.TH = TH; c.TW = 20; c.WN = WN; c.NREP = NREP; c.lds = lds; c.pk = 1; c.pk_wgpc = wgpc; c.pk_wstat = wstat;
@@ -216,7 +224,7 @@ static bool choose_pk2_cfg(int dtype, const ConvRow& r, int max_batch, ConvCfg& 
                     if (wide) {
                         const double patch = (double)(2 * TH + 1) * 48 * 64 * c.nchunks, wbytes = (double)NTB * 9 * 1024 * c.nchunks;
                         const bool resident = wstat || c.nchunks <= 2;
-                        t_ing = ((double)NT * gy * (patch + (resident ? 0.0 : wbytes)) + (resident ? (double)G * gy * wbytes : 0.0)) / 4.0e12;
+                        t_ing = ((double)NT * gy * (patch + (resident ? 0.0 : wbytes)) + (resident ? (double)G * gy * wbytes : 0.0)) / 8.0e12;
                     }
                     const double cost = std::max(std::max(t_comp, t_mem), t_ing) + 0.15 * std::min(t_comp, t_mem) + 4e-6;
                     if (cost < best) {

@@ -208,7 +208,9 @@ void pack_conv_fold(int dtype, const ConvRow& rU, const ConvRow& rV, const ConvC
 size_t packed_stem_toeplitz_bytes(int dtype) { return (size_t)2 * 4 * 3 * (dtype == VTI_F16 ? 1 : 2) * 1024; }
 
 void pack_stem_toeplitz(int dtype, const ConvRow& r0, const float* w, const float* b, uint8_t* dst, float* bd, float* alpha) {
-    const bool f16 = dtype == VTI_F16;
+    // h2: the kernel's pixel operand is the byte's INTEGER value in plain fp16 (exact), so the fragments use the fp16 K layout and carry
+    // w / 255 as two planes: hi = fp16(w' SW), lo = fp16(w' SW - hi); alpha = 1 / SW (the operand is not scaled by 16 here)
+    const bool f16 = dtype == VTI_F16 || dtype == VTI_H2;
     const int KC = f16 ? 32 : 16, VEC = f16 ? 8 : 4, NCH = 32 / KC;
     std::vector<float> pv((size_t)2 * 4 * 3 * NCH * 64 * VEC);
     for (int sw = 0; sw < 2; ++sw)
@@ -223,11 +225,29 @@ void pack_stem_toeplitz(int dtype, const ConvRow& r0, const float* w, const floa
                             if (t >= 0 && t < 9 && co < r0.c2) {
                                 const int kw = t / 3, m = t % 3, chn = sw ? 2 - m : m;
                                 v = w[(((size_t)co * 3 + chn) * 3 + kh) * 3 + kw];
+                                if (dtype == VTI_H2) v = (float)((double)v / 255.0);
                             }
                             const size_t e = ((((((size_t)sw * 4 + pp) * 3 + kh) * NCH + c) * 64) + lane) * VEC + j;
                             pv[e] = v;
                         }
-    emit_packed(dtype, pv, dst, alpha);
+    if (dtype == VTI_H2) {
+        float mx = 0.f;
+        for (float x : pv) mx = std::max(mx, std::fabs(x));
+        int e = 0;
+        if (mx > 0.f) (void)std::frexp(mx, &e);
+        const float sc = mx > 0.f ? std::ldexp(1.0f, 14 - e) : 1.0f;
+        const size_t frag = (size_t)64 * VEC;                      // elements of one (sw, pp, kh) fragment
+        for (size_t f = 0; f < pv.size() / frag; ++f)
+            for (size_t i = 0; i < frag; ++i) {
+                const float sv = pv[f * frag + i] * sc;
+                const _Float16 hi = (_Float16)sv, lo = (_Float16)(sv - (float)hi);
+                ((_Float16*)dst)[(2 * f) * frag + i] = hi;         // plane 0
+                ((_Float16*)dst)[(2 * f + 1) * frag + i] = lo;     // plane 1
+            }
+        if (alpha) *alpha = 1.0f / sc;
+    } else {
+        emit_packed(dtype, pv, dst, alpha);
+    }
     for (int n = 0; n < 16; ++n) bd[n] = n < r0.c2 ? b[n] : 0.f;
 }
 
