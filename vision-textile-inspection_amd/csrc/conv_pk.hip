@@ -469,16 +469,21 @@ __global__ __launch_bounds__(512) void conv3_pk(const ConvParams p) {
 //  * weights stay in LDS for the whole launch when all K chunks of the workgroup's n-group fit (`pk_wstat`),
 //    otherwise the chunk of a step travels with its pixels in the ring.
 // One raw s_barrier per (tile, chunk) step.
+//  * CPS chunks per step (4-byte storage: 2): a K chunk of the fp32 / h2 engines is 16 channels, i.e. 10 NREP (h2: 20 NREP) MFMAs
+//    per wave between two barriers -- on the K = 256..512 layers of the 20x20 / 40x40 maps (16-32 steps per tile) the barrier, the
+//    operand reads' latency and, for h2, the operand preparation in front of every step's MFMAs were 3/4 of a step (stamps:
+//    2.2 k cycles per step for 640 cycles of MFMAs).  A step now carries two chunks (two 64-B slot images per stage): half the
+//    barriers, and h2 prepares the second chunk's operands in the shadow of the first chunk's MFMAs.
 
-constexpr int PK1_MAXP = 5;       // pixel DMA pieces per loader wave and step (80 px = 5 pieces per M-wave, WN >= 1)
+constexpr int PK1_MAXP = 5;       // pixel DMA pieces per loader wave, chunk and step (80 px = 5 pieces per M-wave, WN >= 1)
 
-size_t conv1_pk_lds_bytes(int nwm, int WN, int NREP, int nchunks, int depth, int wstat) {
-    const size_t stage = (size_t)nwm * 80 * 64;
+size_t conv1_pk_lds_bytes(int nwm, int WN, int NREP, int nchunks, int depth, int wstat, int cps) {
+    const size_t stage = (size_t)nwm * 80 * 64 * cps;
     const size_t wch = (size_t)WN * NREP * 1024;
-    return (size_t)depth * stage + (wstat ? (size_t)nchunks * wch : (size_t)depth * wch) + 1024 /*dummy*/ + (size_t)WN * NREP * 64;
+    return (size_t)depth * stage + (wstat ? (size_t)nchunks * wch : (size_t)depth * wch * cps) + 1024 /*dummy*/ + (size_t)WN * NREP * 64;
 }
 
-template <typename T, int NREP, int WN>
+template <typename T, int NREP, int WN, int CPS>
 __global__ __launch_bounds__(512) void conv1_pk(const ConvParams p) {
     using vec = typename Tr<T>::vec;
     constexpr int VEC = Tr<T>::VEC, KC = Tr<T>::KC, ES = (int)sizeof(T);
@@ -495,10 +500,12 @@ __global__ __launch_bounds__(512) void conv1_pk(const ConvParams p) {
     const int nld = (int)(blockDim.x >> 6) - ncomp;
     const int D = p.pk_depth;
     const int tile_px = nwm * 80;
-    const int stage_bytes = tile_px * 64;
+    const int img_bytes = tile_px * 64;                     // one chunk's slot image
+    const int stage_bytes = img_bytes * CPS;
     const int npieces = tile_px / 16;
     const int wbuf_off = D * stage_bytes;
-    const int dummy_off = wbuf_off + (p.pk_wstat ? p.nchunks : D) * WCH;
+    const int dummy_off = wbuf_off + (p.pk_wstat ? p.nchunks : D * CPS) * WCH;
+    const int spt = (p.nchunks + CPS - 1) / CPS;            // steps per tile
     const int bias_off = dummy_off + 1024;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
     const int nt0 = blockIdx.y * NTB;
@@ -518,7 +525,7 @@ __global__ __launch_bounds__(512) void conv1_pk(const ConvParams p) {
     }
     if (t >= tend) return;
     const int ntiles_mine = (tend - t + tstride - 1) / tstride;
-    const int nsteps = ntiles_mine * p.nchunks;
+    const int nsteps = ntiles_mine * spt;
 
     if (wave >= ncomp) {
         // =================== loader waves ===================
@@ -529,14 +536,14 @@ __global__ __launch_bounds__(512) void conv1_pk(const ConvParams p) {
         const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.wpk, 0, (int)p.wpk_bytes, 0x00020000);
         const int ppl = (npieces + nld - 1) / nld;                      // pixel pieces per loader and step (<= PK1_MAXP)
         const int wpl = p.pk_wstat ? 0 : (NTB + nld - 1) / nld;         // weight pieces per loader and step
-        const int per_step = ppl + wpl;
+        const int per_step = CPS * (ppl + wpl);
         const __amdgpu_buffer_rsrc_t rsA2 = __builtin_amdgcn_make_buffer_rsrc((void*)p.in2, 0, (int)p.in2_bytes, 0x00020000);
         // per-lane source offsets of this loader's pieces, recomputed when the chain moves to the next tile: vo1 = the conv's
         // own input; vo2 = the low-resolution source of the folded Upsample (pixel (y >> 1, x >> 1) of the same frame)
         unsigned vo1[PK1_MAXP], vo2[PK1_MAXP];
         int cur_ti = -1;
         auto issue = [&](int s) {                                       // DMA of step s of this workgroup's chain
-            const int ti = s / p.nchunks, c = s - ti * p.nchunks;
+            const int ti = s / spt, cs = s - ti * spt;
             if (ti != cur_ti) {
                 cur_ti = ti;
                 const int pix0 = (t + ti * tstride) * tile_px;
@@ -557,24 +564,31 @@ __global__ __launch_bounds__(512) void conv1_pk(const ConvParams p) {
                 }
             }
             const int slot = s % D;
-            const bool qok = c < cvalid;
-            const bool from_up = c * KC < p.up_C;                      // chunk granularity: up_C is a multiple of KC
-            const unsigned dst = lds0 + slot * stage_bytes;
 #pragma unroll
-            for (int u = 0; u < PK1_MAXP; ++u) {
-                if (u >= ppl) break;
-                const int piece = lw + u * nld;
-                const unsigned vo = qok ? (from_up ? vo2[u] : vo1[u]) : OOB;
-                const unsigned ld = piece < npieces ? dst + piece * 1024 : lds0 + dummy_off;
-                if (from_up) dma16(rsA2, vo, (unsigned)(c * KC * ES), ld);
-                else dma16(rsA, vo, (unsigned)(c * KC * ES), ld);
-            }
-            if (wpl) {
-                const unsigned src = (unsigned)(((size_t)c * p.ntiles_n + nt0) * 1024);
-                const unsigned wd = lds0 + wbuf_off + slot * WCH;
-                for (int u = 0; u < wpl; ++u) {
-                    const int f = lw + u * nld;
-                    dma16(rsB, f < NTB ? (unsigned)lane * 16u : OOB, src + f * 1024, f < NTB ? wd + f * 1024 : lds0 + dummy_off);
+            for (int cc = 0; cc < CPS; ++cc) {
+                // a chunk past the last one (odd chunk count) is issued all the same -- every step must issue the same number of DMA
+                // instructions for the counted wait -- with every lane out of range: zeros, which the compute waves do not read
+                const int c = cs * CPS + cc;
+                const bool live = c < p.nchunks;
+                const bool qok = c < cvalid && live;
+                const bool from_up = c * KC < p.up_C;                  // chunk granularity: up_C is a multiple of KC
+                const unsigned dst = lds0 + slot * stage_bytes + cc * img_bytes;
+#pragma unroll
+                for (int u = 0; u < PK1_MAXP; ++u) {
+                    if (u >= ppl) break;
+                    const int piece = lw + u * nld;
+                    const unsigned vo = qok ? (from_up ? vo2[u] : vo1[u]) : OOB;
+                    const unsigned ld = piece < npieces ? dst + piece * 1024 : lds0 + dummy_off;
+                    if (from_up) dma16(rsA2, vo, (unsigned)(c * KC * ES), ld);
+                    else dma16(rsA, vo, (unsigned)(c * KC * ES), ld);
+                }
+                if (wpl) {
+                    const unsigned src = (unsigned)(((size_t)(live ? c : 0) * p.ntiles_n + nt0) * 1024);
+                    const unsigned wd = lds0 + wbuf_off + (slot * CPS + cc) * WCH;
+                    for (int u = 0; u < wpl; ++u) {
+                        const int f = lw + u * nld;
+                        dma16(rsB, (f < NTB && live) ? (unsigned)lane * 16u : OOB, src + f * 1024, f < NTB ? wd + f * 1024 : lds0 + dummy_off);
+                    }
                 }
             }
         };
@@ -615,22 +629,75 @@ __global__ __launch_bounds__(512) void conv1_pk(const ConvParams p) {
         for (int m = 0; m < MREP; ++m)
 #pragma unroll
             for (int n = 0; n < NREP; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        for (int c = 0; c < p.nchunks; ++c, ++s) {
+        for (int cs = 0; cs < spt; ++cs, ++s) {
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             const int slot = s % D;
-            const char* sx = smem + slot * stage_bytes;
-            const char* sw = smem + wbuf_off + (p.pk_wstat ? c : slot) * WCH + wn * (NREP * 1024) + lane * 16;
-            vec w[NREP];
+            const int ncc = min(CPS, p.nchunks - cs * CPS);         // live chunks of this step (wave-uniform)
+            if constexpr (Tr<T>::H2) {
+                // units u = (chunk of the step, n-tile): raw fragment read two units ahead, WH / WL prepared during the previous unit's
+                // 2 x MREP MFMAs (one VALU per MFMA), pixel fragments of the next chunk read under the current chunk's last unit
+                constexpr int NU = CPS * NREP;
+                const int nu = ncc * NREP;
+                auto wptr = [&](int u) -> const char* {
+                    const int cc = u / NREP, n = u - cc * NREP;
+                    return smem + wbuf_off + (p.pk_wstat ? cs * CPS + cc : slot * CPS + cc) * WCH + (wn * NREP + n) * 1024 + lane * 16;
+                };
+                u32x4 wraw[2], wh[2], wl[2];
+                h2x4 x[2][MREP];
+                wraw[0] = *(const u32x4*)wptr(0);
+                if (nu > 1) wraw[1] = *(const u32x4*)wptr(1);
 #pragma unroll
-            for (int n = 0; n < NREP; ++n) w[n] = *(const vec*)(sw + n * 1024);
-            vec x[MREP];
+                for (int m = 0; m < MREP; ++m) x[0][m] = *(const h2x4*)(smem + slot * stage_bytes + xa[m]);
 #pragma unroll
-            for (int m = 0; m < MREP; ++m) x[m] = *(const vec*)(sx + xa[m]);
+                for (int i = 0; i < 4; ++i) { wh[0][i] = __builtin_amdgcn_perm(wraw[0][i], wraw[0][i], 0x01000100u); wl[0][i] = wraw[0][i] >> 16; }
 #pragma unroll
-            for (int m = 0; m < MREP; ++m)
+                for (int u = 0; u < NU; ++u) {
+                    if (u < nu) {
+                        const int cc = u / NREP, n = u % NREP, cur = u & 1, nxt = cur ^ 1;
+                        if (n == 0 && cc + 1 < CPS && cc + 1 < ncc) {
 #pragma unroll
-                for (int n = 0; n < NREP; ++n) acc[m][n] = mma(w[n], x[m], acc[m][n]);
+                            for (int m = 0; m < MREP; ++m) x[(cc + 1) & 1][m] = *(const h2x4*)(smem + slot * stage_bytes + (cc + 1) * img_bytes + xa[m]);
+                        }
+                        u32x4 wnext = wraw[nxt];                       // raw fragment of unit u + 1 (read at unit u - 1)
+                        if (u + 2 < nu) wraw[cur] = *(const u32x4*)wptr(u + 2);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int j = 0; j < 2 * MREP; ++j) {
+                            const int m = j >> 1;
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, (j & 1) ? wl[cur] : wh[cur]),
+                                                                               __builtin_bit_cast(half8, x[cc & 1][m].u), acc[m][n], 0, 0, 0);
+                            if (j < 8 && u + 1 < nu) {
+                                const int i = j & 3;
+                                if (j < 4) wh[nxt][i] = __builtin_amdgcn_perm(wnext[i], wnext[i], 0x01000100u);
+                                else wl[nxt][i] = wnext[i] >> 16;
+                                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                                __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int cc = 0; cc < CPS; ++cc) {
+                    if (cc < ncc) {
+                        const int c = cs * CPS + cc;
+                        const char* sx = smem + slot * stage_bytes + cc * img_bytes;
+                        const char* sw = smem + wbuf_off + (p.pk_wstat ? c : slot * CPS + cc) * WCH + wn * (NREP * 1024) + lane * 16;
+                        vec w[NREP];
+#pragma unroll
+                        for (int n = 0; n < NREP; ++n) w[n] = *(const vec*)(sw + n * 1024);
+                        vec x[MREP];
+#pragma unroll
+                        for (int m = 0; m < MREP; ++m) x[m] = *(const vec*)(sx + xa[m]);
+#pragma unroll
+                        for (int m = 0; m < MREP; ++m)
+#pragma unroll
+                            for (int n = 0; n < NREP; ++n) acc[m][n] = mma(w[n], x[m], acc[m][n]);
+                    }
+                }
+            }
         }
         const int pix0 = (t + ti * tstride) * tile_px + wm * 80;
         if (fast_epi) {
@@ -732,7 +799,9 @@ bool conv_pk_instantiated(int nrep, int wn) {
 
 template <typename T, int NREP, int WN>
 static hipError_t launch_pk1_one(const ConvParams& p, dim3 grid, int threads, size_t lds, hipStream_t st) {
-    auto k = conv1_pk<T, NREP, WN>;
+    constexpr int CPS = sizeof(T) == 2 ? 1 : 2;            // chunks per step: the planner sets pk_cps to the same value
+    if (p.pk_cps != CPS) return hipErrorInvalidValue;
+    auto k = conv1_pk<T, NREP, WN, CPS>;
     static bool attr_done_dev[kMaxDevices] = {};
     bool& attr_done = attr_done_dev[current_device_slot()];
     if (!attr_done) {
@@ -746,14 +815,14 @@ static hipError_t launch_pk1_one(const ConvParams& p, dim3 grid, int threads, si
 
 bool conv1_pk_instantiated(int nrep, int wn) { return conv_pk_instantiated(nrep, wn) || (wn == 4 && nrep == 4); }
 
-bool conv1_pk_fits(int nwm, int WN, int NREP, int nchunks, int depth, int wstat) {
+bool conv1_pk_fits(int nwm, int WN, int NREP, int nchunks, int depth, int wstat, int cps) {
     const int ncomp = nwm * WN;
-    if (nwm < 1 || ncomp > 4 || depth < 2 || depth > 8) return false;
+    if (nwm < 1 || ncomp > 4 || depth < 2 || depth > 8 || cps < 1 || cps > 2) return false;
     const int npieces = nwm * 5;
     if ((npieces + ncomp - 1) / ncomp > PK1_MAXP) return false;
-    const int per_step = (npieces + ncomp - 1) / ncomp + (wstat ? 0 : (WN * NREP + ncomp - 1) / ncomp);
+    const int per_step = cps * ((npieces + ncomp - 1) / ncomp + (wstat ? 0 : (WN * NREP + ncomp - 1) / ncomp));
     if (per_step * (depth - 2) > 63) return false;                     // counted s_waitcnt range
-    return conv1_pk_lds_bytes(nwm, WN, NREP, nchunks, depth, wstat) <= 160 * 1024;
+    return conv1_pk_lds_bytes(nwm, WN, NREP, nchunks, depth, wstat, cps) <= 160 * 1024;
 }
 
 template <typename T>
@@ -767,7 +836,7 @@ static hipError_t launch_pk1_t(int nrep, const ConvParams& p, dim3 grid, int thr
 // 1x1: p.TH = compute waves along M, p.TW = 80 (pixels per wave); workgroups as for the 3x3 kernel
 hipError_t launch_conv1_pk(int dtype, int nrep, const ConvParams& p, size_t lds_bytes, hipStream_t st) {
     const int NTB = p.WN * nrep;
-    if (!conv1_pk_fits(p.TH, p.WN, nrep, p.nchunks, p.pk_depth, p.pk_wstat)) return hipErrorInvalidValue;
+    if (!conv1_pk_fits(p.TH, p.WN, nrep, p.nchunks, p.pk_depth, p.pk_wstat, p.pk_cps)) return hipErrorInvalidValue;
     if (p.ntiles_n % NTB || p.pk_wgs < 1 || (p.pk_xcd && p.pk_wgs % 8) || p.has_res) return hipErrorInvalidValue;
     if ((size_t)p.in_bytes >= 0x80000000u || (size_t)p.out_bytes >= 0x80000000u) return hipErrorInvalidValue;
     if (p.pk_tiles == 0) return hipSuccess;

@@ -247,6 +247,7 @@ static bool choose_pk2_cfg(int dtype, const ConvRow& r, int max_batch, ConvCfg& 
 // weights stationary in LDS when all K chunks of the n-group fit in 64 KB.  These layers are HBM-bound: prefer one
 // n-group (the pixels are read once), then the deepest ring, then the fewest rounds.
 static bool choose_pk1_cfg(int esize, const ConvRow& r, int max_batch, ConvCfg& c, int fth, int fwn, int fnrep) {
+    const int cps = esize == 2 ? 1 : 2;        // K chunks per step (conv_pk.hip: launch_pk1_one instantiates the same value per type)
     const char* no = getenv("VTI_NO_PK1");
     if (no && no[0] == '1') return false;
     const bool deconv = r.kind == 2;
@@ -277,25 +278,34 @@ static bool choose_pk1_cfg(int esize, const ConvRow& r, int max_batch, ConvCfg& 
                 // 40x40: 8 of every 18 KB per step; 36.5 -> 32.6 us with 96 KB stationary and a 6-deep ring).  VTI_PK1_WSTAT_KB: tools/pk1_sweep.py
                 static const size_t wstat_max = getenv("VTI_PK1_WSTAT_KB") ? (size_t)atoi(getenv("VTI_PK1_WSTAT_KB")) * 1024 : 96 * 1024;
                 const int wstat = (size_t)c.nchunks * NTB * 1024 <= wstat_max ? 1 : 0;
-                int depth = 0;
-                for (int dd = 8; dd >= 2; --dd) if (conv1_pk_fits(nwm, WN, NREP, c.nchunks, dd, wstat)) { depth = dd; break; }
-                if (!depth) continue;
-                const long NT = (total_px + nwm * 80 - 1) / (nwm * 80);
-                long G = std::min<long>(NT, std::max(1, 256 / gy));
-                if (G >= 8) G &= ~7L;
-                const long rounds = (NT + G - 1) / G;
-                const double step_cyc = 5.0 * NREP * 16 + 250;
-                const double t_comp = rounds * (c.nchunks * step_cyc + 1100.0 * NREP) * ((ncomp + 3) / 4) / 1.9e9;
-                const double bytes = (double)total_px * ((double)gy * r.c1 + (double)c.gemm_n) * esize +
-                                     (wstat ? 0.0 : (double)NT * gy * c.nchunks * NTB * 1024 * 0.25);   // streamed weights (L2)
-                const double inflight = (double)(depth - 1) * nwm * 80 * 64;                       // bytes in flight per CU
-                static const double inflight_full = getenv("VTI_PK1_INFLIGHT_KB") ? atof(getenv("VTI_PK1_INFLIGHT_KB")) * 1e3 : 50e3;       // bytes in flight per CU that saturate the ingest (measured: ~50 KB)
-                const double t_mem = bytes / (5.0e12 * std::min(1.0, inflight / inflight_full));
-                const double cost = std::max(t_comp, t_mem) + 0.15 * std::min(t_comp, t_mem) + 4e-6;
-                if (cost < best) {
-                    best = cost; found = true;
-                    c.TH = nwm; c.TW = 80; c.WN = WN; c.NREP = NREP; c.pk = 2; c.pk_wgpc = 1; c.pk_depth = depth; c.pk_wstat = wstat;
-                    c.lds = conv1_pk_lds_bytes(nwm, WN, NREP, c.nchunks, depth, wstat);
+                // one workgroup per CU with the deepest ring that fits -- or (4-byte storage) two co-resident workgroups with half the LDS each:
+                // the same bytes in flight per CU, and one workgroup's MFMAs + epilogue run under the other's waits (as for conv3_pk: `solo`)
+                static const bool no_w2 = getenv("VTI_PK1_NO_WGPC2") && getenv("VTI_PK1_NO_WGPC2")[0] == '1';
+                static const bool force_w2 = getenv("VTI_PK1_FORCE_WGPC2") && getenv("VTI_PK1_FORCE_WGPC2")[0] == '1';     // A/B aid
+                for (int wgpc = (esize == 4 && force_w2) ? 2 : 1; wgpc <= ((esize == 4 && !no_w2) ? 2 : 1); ++wgpc) {
+                    int depth = 0;
+                    for (int dd = 8; dd >= 2; --dd)
+                        if (conv1_pk_fits(nwm, WN, NREP, c.nchunks, dd, wstat, cps) &&
+                            conv1_pk_lds_bytes(nwm, WN, NREP, c.nchunks, dd, wstat, cps) <= (size_t)(160 * 1024) / wgpc) { depth = dd; break; }
+                    if (!depth) continue;
+                    const long NT = (total_px + nwm * 80 - 1) / (nwm * 80);
+                    long G = std::min<long>(NT, std::max(1, 256 * wgpc / gy));
+                    if (G >= 8) G &= ~7L;
+                    const long rounds = (NT + G - 1) / G;
+                    const double solo = esize == 4 ? ((ncomp * wgpc > 4) ? 1.1 : 1.45) : 1.0;
+                    const double step_cyc = 5.0 * NREP * 16 * solo * (esize == 4 ? 2.0 : 1.0) + 250.0 / cps;
+                    const double t_comp = rounds * (c.nchunks * step_cyc + 1100.0 * NREP) * ((ncomp * wgpc + 3) / 4) / 1.9e9;
+                    const double bytes = (double)total_px * ((double)gy * r.c1 + (double)c.gemm_n) * esize +
+                                         (wstat ? 0.0 : (double)NT * gy * c.nchunks * NTB * 1024 * 0.25);   // streamed weights (L2)
+                    const double inflight = (double)wgpc * (depth - 1) * nwm * 80 * 64 * cps;          // bytes in flight per CU
+                    static const double inflight_full = getenv("VTI_PK1_INFLIGHT_KB") ? atof(getenv("VTI_PK1_INFLIGHT_KB")) * 1e3 : 50e3;       // bytes in flight per CU that saturate the ingest (measured: ~50 KB)
+                    const double t_mem = bytes / (5.0e12 * std::min(1.0, inflight / inflight_full));
+                    const double cost = std::max(t_comp, t_mem) + 0.15 * std::min(t_comp, t_mem) + 4e-6;
+                    if (cost < best) {
+                        best = cost; found = true;
+                        c.TH = nwm; c.TW = 80; c.WN = WN; c.NREP = NREP; c.pk = 2; c.pk_wgpc = wgpc; c.pk_depth = depth; c.pk_wstat = wstat; c.pk_cps = cps;
+                        c.lds = conv1_pk_lds_bytes(nwm, WN, NREP, c.nchunks, depth, wstat, cps);
+                    }
                 }
             }
         }

@@ -282,7 +282,7 @@ static void fill_conv_params(int conv_elem_size, ConvParams& p, const ConvRow& r
         const size_t ob = (deconv ? 4 * npx : npx) * out_ld * (out_f32 ? 4 : es);
         p.pk = (ib < 0x80000000ull && ob < 0x80000000ull && !res) ? 2 : 0;
         p.in_bytes = (unsigned)ib; p.out_bytes = (unsigned)ob; p.res_bytes = 0;
-        p.pk_depth = g.pk_depth; p.pk_wstat = g.pk_wstat;
+        p.pk_depth = g.pk_depth; p.pk_wstat = g.pk_wstat; p.pk_cps = g.pk_cps;
         p.pk_tiles = (int)((npx + (size_t)g.TH * 80 - 1) / ((size_t)g.TH * 80));
         const int gy = g.ntiles_n / (g.WN * g.NREP);
         int G = std::min(p.pk_tiles, std::max(1, 256 * g.pk_wgpc / gy));

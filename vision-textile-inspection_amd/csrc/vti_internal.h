@@ -61,6 +61,7 @@ struct ConvCfg {         // launch geometry chosen at plan time
     // persistent LDS-DMA kernel (conv_pk.hip): TW = 20, TH = 4 * M-waves; wgpc = co-resident workgroups per CU
     int pk = 0, pk_wgpc = 1;         // pk: 1 = conv3_pk, 2 = conv1_pk (TH = compute waves along M, TW = 80), 3 = bneck_pk (fused 3x3 -> 3x3 pair), 4 = conv3_pk stride 2
     int pk_depth = 2, pk_wstat = 0;  // conv1_pk: stage-ring depth, weights stationary in LDS
+    int pk_cps = 1;                  // conv1_pk: K chunks per step
     int threads = 256;               // per-tile kernel: 256, or 512 (fused towers on wide maps: one 8-wave workgroup per CU, 16 x 40 tiles)
 };
 
@@ -126,6 +127,7 @@ struct ConvParams {
     float dfl_stride;
     // persistent kernel (conv_pk.hip): tile count, workgroups along x, XCD-contiguous tile ranges, tensor sizes
     int pk, pk_tiles, pk_wgs, pk_xcd, pk_depth, pk_wstat, pk_lin /* 1: linear pixel -> column-tile map (A/B aid) */;
+    int pk_cps;                          // conv1_pk: K chunks per step (1 fp16, 2 for 4-byte storage)
     unsigned in_bytes, out_bytes, res_bytes, out2_bytes;
     // conv1_pk: channels [0, up_C) come from in2 [B, Hout/2, Wout/2, in2_ld] at (y >> 1, x >> 1): the neck's Upsample + Concat folded into the loads
     const void* in2; int in2_ld, in2_coff, up_C; unsigned in2_bytes;
@@ -174,8 +176,8 @@ int conv_pk2_depth(int TH, int WN, int NREP, int nchunks, int wstat = 0);
 bool conv_pk_fits(int TH, int WN, int NREP, int nchunks, int wstat = 0);
 bool conv_pk_instantiated(int nrep, int wn);
 hipError_t launch_conv1_pk(int dtype, int nrep, const ConvParams& p, size_t lds_bytes, hipStream_t st);
-size_t conv1_pk_lds_bytes(int nwm, int WN, int NREP, int nchunks, int depth, int wstat);
-bool conv1_pk_fits(int nwm, int WN, int NREP, int nchunks, int depth, int wstat);
+size_t conv1_pk_lds_bytes(int nwm, int WN, int NREP, int nchunks, int depth, int wstat, int cps = 1);   // cps: K chunks per step
+bool conv1_pk_fits(int nwm, int WN, int NREP, int nchunks, int depth, int wstat, int cps = 1);
 bool conv1_pk_instantiated(int nrep, int wn);
 hipError_t launch_bneck_pk(int dtype, int nrep, const ConvParams& p, size_t lds_bytes, hipStream_t st);
 size_t bneck_pk_lds_bytes(int TH, int NREP);
