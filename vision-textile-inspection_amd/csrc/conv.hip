@@ -182,7 +182,9 @@ __global__ __launch_bounds__(NT, NT == 512 ? 1 : 2) void conv_kernel(const ConvP
                     w[n] = *(const vec*)(smB + ((wn * NREP + n) * TAPS + tp) * 1024 + lane * 16);
             };
             // (h2_taps keeps two prepared operand sets: 16 NREP registers more than the plain loop, which spills at NREP = 5 and at
-            // NREP = 4 with 256 threads -- those keep the plain loop, whose v_perms sit in front of each tap's MFMAs)
+            // NREP = 4 with 256 threads -- those keep the plain loop, whose operand preparation sits in front of each tap's MFMAs; the
+            // register-lean h2_taps_nmajor of the persistent kernel was SLOWER here: 235 -> 286 us on the P3 class tower, the fused
+            // stage's 100 + 100 accumulators spill either way and its two pixel-fragment sets add to it)
             if constexpr (Tr<T>::H2 && TAPS > 1 && (NREP <= 3 || (NREP == 4 && NT == 512))) {
                 auto ldw1 = [&](int tp, int n) -> vec { return *(const vec*)(smB + ((wn * NREP + n) * TAPS + tp) * 1024 + lane * 16); };
                 h2_taps<NREP, MREP, TAPS, 3>(acc, ldx, ldw1);

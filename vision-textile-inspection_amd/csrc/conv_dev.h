@@ -164,6 +164,49 @@ __device__ __forceinline__ void h2_taps(f32x4 (&acc)[M][NREP], LDX ldx, LDW ldw)
     }
 }
 
+// The same loop for LARGE register tiles (NREP = 5: 100 accumulator registers): h2_taps keeps two prepared operand sets of NREP
+// fragments (16 NREP registers), which spills there.  Here the work of a chunk is walked n-tile-major inside a tap -- unit u = (tap, n) =
+// 2 M MFMAs on one weight fragment -- so that only ONE fragment is prepared ahead (under the current unit's MFMAs) and one raw fragment
+// is in flight behind it; the M pixel fragments of a tap stay in registers for its NREP units and the next tap's are read during the
+// tap's last unit.
+template <int NREP, int M, int TAPS, class LDX, class LDW>
+__device__ __forceinline__ void h2_taps_nmajor(f32x4 (&acc)[M][NREP], LDX ldx, LDW ldw) {
+    constexpr int NU = TAPS * NREP;
+    h2x4 x[2][M];
+    u32x4 wraw[2], wh[2], wl[2];
+#pragma unroll
+    for (int m = 0; m < M; ++m) x[0][m] = ldx(m);
+    wraw[0] = ldw(0, 0).u;
+    if (NU > 1) wraw[1] = ldw(1 / NREP, 1 % NREP).u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { wh[0][i] = __builtin_amdgcn_perm(wraw[0][i], wraw[0][i], 0x01000100u); wl[0][i] = wraw[0][i] >> 16; }
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        const int tp = u / NREP, n = u % NREP, cur = u & 1, nxt = cur ^ 1;
+        if (n == NREP - 1 && tp + 1 < TAPS) {
+#pragma unroll
+            for (int m = 0; m < M; ++m) x[(tp + 1) & 1][m] = ldx((tp + 1) * M + m);
+        }
+        const u32x4 wnext = wraw[nxt];
+        if (u + 2 < NU) wraw[cur] = ldw((u + 2) / NREP, (u + 2) % NREP).u;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 2 * M; ++j) {
+            const int m = j >> 1;
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, (j & 1) ? wl[cur] : wh[cur]),
+                                                               __builtin_bit_cast(half8, x[tp & 1][m].u), acc[m][n], 0, 0, 0);
+            if (j < 8 && u + 1 < NU) {
+                const int i = j & 3;
+                if (j < 4) wh[nxt][i] = __builtin_amdgcn_perm(wnext[i], wnext[i], 0x01000100u);
+                else wl[nxt][i] = wnext[i] >> 16;
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // SiLU.  fp32 engine (parity mode): IEEE exp + division, as the CPU reference computes it.
 // fp16 engine: v_exp_f32 + v_rcp_f32 (each ~1 ulp in f32, far below the fp16 rounding that follows);
 // the accurate form costs ~30 VALU instructions per element and dominated the kernel's issue slots.

@@ -323,7 +323,8 @@ __global__ __launch_bounds__(512) void conv3_pk(const ConvParams p) {
 #ifndef H2_XD
 #define H2_XD (NREP >= 4 ? 3 : 4)
 #endif
-                    h2_taps<NREP, MREP, TAPS, H2_XD>(acc, ldx, ldw1);
+                    if constexpr (NREP >= 5) h2_taps_nmajor<NREP, MREP, TAPS>(acc, ldx, ldw1);
+                    else h2_taps<NREP, MREP, TAPS, H2_XD>(acc, ldx, ldw1);
                 } else {
                 ldw(0, wq[0]);
 #pragma unroll

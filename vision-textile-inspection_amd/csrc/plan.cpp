@@ -123,7 +123,8 @@ static bool choose_pk_cfg(int dtype, const ConvRow& r, int max_batch, ConvCfg& c
         for (int NREP = 1; NREP <= 5; ++NREP) {
             if (fnrep && NREP != fnrep) continue;
             if (!conv_pk_instantiated(NREP, WN)) continue;
-            if (dtype == VTI_H2 && NREP == 5 && !fnrep) continue;       // h2 at NREP = 5 spills (two prepared operand sets beside 100 accumulators)
+            static const bool h2_no_n5 = getenv("VTI_H2_NO_N5") && getenv("VTI_H2_NO_N5")[0] == '1';      // A/B aid (h2 at NREP = 5 runs h2_taps_nmajor)
+            if (dtype == VTI_H2 && NREP == 5 && !fnrep && h2_no_n5) continue;
             const int NTB = WN * NREP;
             const int gy = (c.ntiles_n + NTB - 1) / NTB;
             const double n_eff = (double)c.ntiles_n / (gy * NTB);
@@ -759,7 +760,12 @@ std::string Plan::build(const vti_desc& d) {
         else if (op.fused_l1 >= 0) choose_conv_cfg(d.dtype, r, true, d.max_batch, op.cfg, 0, 0, 1, 1);   // one 16-channel n-tile: stem_l1_kernel's weight indexing
         else if (op.fused >= 0) {   // whole Cout in one wave; the per-tile kernel (2 workgroups per CU) hides the long fused epilogue better
             const char* pf = getenv("VTI_PK_FUSED");
-            choose_conv_cfg(d.dtype, r, false, d.max_batch, op.cfg, 0, 0, 1, r.c2 / 16, pk_ok && pf && pf[0] == '1');
+            // VTI_PK_FUSED: 1 = every fused op on the persistent schedule, 2 = those whose register tile leaves room for the fused stage
+            // (NREP <= 4: the 80-channel class towers spill there)
+            // h2: the 64-channel box towers run the fused stage on the persistent schedule by default (A/B on one box: 150 -> 137 us at P3,
+            // 41 -> 30 us at P5; the 32-channel coefficient towers lose 1-2 us there and stay on the per-tile kernel)
+            const bool pkf = pf ? (pf[0] == '1' || (pf[0] == '2' && r.c2 / 16 <= 4)) : (d.dtype == VTI_H2 && r.c2 / 16 == 4);
+            choose_conv_cfg(d.dtype, r, false, d.max_batch, op.cfg, 0, 0, 1, r.c2 / 16, pk_ok && pkf);
             // 8-wave workgroups on 16 x 40 tiles where such tiles cover the map as well as the chosen ones (the 80-wide level: most
             // of the towers' time): half the weight staging per pixel (conv.hip, NT = 512)
             const char* n5 = getenv("VTI_NO_T512");
