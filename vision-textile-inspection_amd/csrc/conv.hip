@@ -246,16 +246,20 @@ bool convfold_supported(int c_in, int c_mid, int c_out, int ntiles2) {
     return c_in == c_mid && c_mid % 16 == 0 && c_out == 64 && c_in % 16 == 0 && c_in <= 64 && (ntiles2 == 1 || ntiles2 == 2 || ntiles2 == 4);
 }
 
-template <typename T, int NREP2>
-__global__ __launch_bounds__(256, 2) void convfold_kernel(const ConvParams p) {
+// NT = 512 (4-byte storage, VTI_FOLD512=1): TWO groups of four phase waves on an 8 x 20 tile share one staged weight chunk.  The composed
+// weights are 64 KB per 16-channel chunk there -- 256 KB per tile for the h2 / fp32 engines, which cannot stay resident: 1.3 GB of L2 -> LDS
+// staging per launch with 80-pixel tiles.  160-pixel tiles halve that -- and the kernel takes the same 272 us: not its bound.  Kept selectable.
+template <typename T, int NREP2, int NT = 256>
+__global__ __launch_bounds__(NT, NT == 512 ? 1 : 2) void convfold_kernel(const ConvParams p) {
     using vec = typename Tr<T>::vec;
     constexpr int VEC = Tr<T>::VEC, KC = Tr<T>::KC;
     constexpr int NREP = 4, TAPS = 4, NTB = 16, AR = 8;
-    constexpr int BR = NTB * TAPS * 64 / 256;                 // 16 weight pieces per thread and chunk
+    constexpr int BR = NTB * TAPS * 64 / NT;                  // weight pieces per thread and chunk (16 / 8)
+    constexpr int PPP = NT / 4;                               // patch pixels per staging pass
     constexpr unsigned OOB = 0xFFFFFFFFu;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, mgrp = tid >> 8;      // wave = output phase, mgrp = which 80 pixels of the tile
     const int py = wave >> 1, px = wave & 1;
     int t = blockIdx.x;
     const int tx = t % p.tiles_x; t /= p.tiles_x;
@@ -273,7 +277,7 @@ __global__ __launch_bounds__(256, 2) void convfold_kernel(const ConvParams p) {
     bool pvalid[MREP];
 #pragma unroll
     for (int m = 0; m < MREP; ++m) {
-        const int pp = m * 16 + (lane & 15);
+        const int pp = (mgrp * MREP + m) * 16 + (lane & 15);
         const bool v = pp < tile_px;
         const int pc = v ? pp : 0;
         const int ly = (int)__umulhi((unsigned)pc, p.tw_magic), lx = pc - ly * p.TW;
@@ -299,7 +303,7 @@ __global__ __launch_bounds__(256, 2) void convfold_kernel(const ConvParams p) {
     unsigned aoff[AR];
 #pragma unroll
     for (int u = 0; u < AR; ++u) {
-        const int pix = pix0 + 64 * u;
+        const int pix = pix0 + PPP * u;
         const int ry = (int)__umulhi((unsigned)pix, p.pw_magic), rx = pix - ry * PW;
         const int y = iy0 + ry, x = ix0 + rx;
         const bool ok = pix < npix && (unsigned)y < (unsigned)p.Hin && (unsigned)x < (unsigned)p.Win;
@@ -310,7 +314,7 @@ __global__ __launch_bounds__(256, 2) void convfold_kernel(const ConvParams p) {
         const bool qok = c < cvalid;
 #pragma unroll
         for (int u = 0; u < AR; ++u)
-            if (pix0 + 64 * u < ((npix + 7) & ~7))
+            if (pix0 + PPP * u < ((npix + 7) & ~7))
                 ra[u] = buf_load16<vec>(rsA, qok ? aoff[u] : OOB, (unsigned)(c * KC * (int)sizeof(T)));
     };
     // the 64 KB of weight fragments of a chunk are fetched inside commit() (short-lived registers, L2-resident data) instead of
@@ -321,14 +325,14 @@ __global__ __launch_bounds__(256, 2) void convfold_kernel(const ConvParams p) {
         for (int h = 0; h < 2; ++h) {
             vec rb[BR / 2];
 #pragma unroll
-            for (int u = 0; u < BR / 2; ++u) rb[u] = buf_load16<vec>(rsB, (unsigned)(tid + (h * (BR / 2) + u) * 256) * 16u, sB);
+            for (int u = 0; u < BR / 2; ++u) rb[u] = buf_load16<vec>(rsB, (unsigned)(tid + (h * (BR / 2) + u) * NT) * 16u, sB);
             if (h == 0) {
 #pragma unroll
                 for (int u = 0; u < AR; ++u)
-                    if (pix0 + 64 * u < npix) *(vec*)(smA + ldsA0 + u * 1024) = ra[u];
+                    if (pix0 + PPP * u < npix) *(vec*)(smA + ldsA0 + u * (PPP * 16)) = ra[u];
             }
 #pragma unroll
-            for (int u = 0; u < BR / 2; ++u) *(vec*)(smB + (tid + (h * (BR / 2) + u) * 256) * 16) = rb[u];
+            for (int u = 0; u < BR / 2; ++u) *(vec*)(smB + (tid + (h * (BR / 2) + u) * NT) * 16) = rb[u];
         }
     };
 
@@ -375,6 +379,26 @@ __global__ __launch_bounds__(256, 2) void convfold_kernel(const ConvParams p) {
 
 template <typename T>
 static hipError_t launch_convfold_t(const ConvParams& p, dim3 grid, size_t lds, hipStream_t st) {
+    if (p.nt == 512) {                  // 8 x 20 tiles, two pixel groups per phase (the plan's choice for 4-byte storage)
+        if constexpr (sizeof(T) == 4) {
+#define VTI_FOLD8(N2)                                                                                                  \
+            if (p.ntiles2 == N2) {                                                                                     \
+                auto k = convfold_kernel<T, N2, 512>;                                                                  \
+                static bool done_dev[kMaxDevices] = {};                                                                \
+                bool& done = done_dev[current_device_slot()];                                                          \
+                if (!done) {                                                                                           \
+                    hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+                    if (e != hipSuccess) return e;                                                                     \
+                    done = true;                                                                                       \
+                }                                                                                                      \
+                hipLaunchKernelGGL(k, grid, dim3(512), lds, st, p);                                                    \
+                return hipGetLastError();                                                                              \
+            }
+            VTI_FOLD8(1) VTI_FOLD8(2) VTI_FOLD8(4)
+#undef VTI_FOLD8
+        }
+        return hipErrorInvalidValue;
+    }
 #define VTI_FOLD(N2)                                                                                                   \
     if (p.ntiles2 == N2) {                                                                                             \
         auto k = convfold_kernel<T, N2>;                                                                               \
@@ -397,7 +421,8 @@ hipError_t launch_convfold(int dtype, const ConvParams& p, size_t lds_bytes, hip
     dim3 grid((unsigned)(p.B * p.tiles_y * p.tiles_x));
     if (grid.x == 0) return hipSuccess;
     // host-side shape guards for the kernel's fixed staging arrays: 80 pixels per workgroup, <= 8 patch pieces per thread
-    if (p.TH * p.TW > MREP * 16 || ((p.TH + 2) * (p.TW + 2) + 7) / 8 * 32 > 256 * 8 || p.Cout != 256 || !p.out2 || !p.fold)
+    const int nthr = p.nt == 512 ? 512 : 256;
+    if (p.TH * p.TW > (nthr / 256) * MREP * 16 || ((p.TH + 2) * (p.TW + 2) + 7) / 8 * 32 > nthr * 8 || p.Cout != 256 || !p.out2 || !p.fold)
         return hipErrorInvalidValue;
     if (dtype == VTI_F16) return launch_convfold_t<half_t>(p, grid, lds_bytes, st);
     if (dtype == VTI_H2) return launch_convfold_t<h2_t>(p, grid, lds_bytes, st);

@@ -112,7 +112,8 @@ static bool choose_pk_cfg(int dtype, const ConvRow& r, int max_batch, ConvCfg& c
     if (no && no[0] == '1') return false;
     if (!(r.k == 3 && r.s == 1 && r.kind != 2) || r.w_out < 20) return false;
     const int esize = dtype == VTI_F16 ? 2 : 4;
-    const bool wide = dtype != VTI_F16;                        // 4-byte elements: ingest-priced search with resident-weight variants
+    static const bool wide16 = getenv("VTI_PK_WIDE16") && getenv("VTI_PK_WIDE16")[0] == '1';      // A/B aid: the same search for fp16
+    const bool wide = dtype != VTI_F16 || wide16;              // 4-byte elements: ingest-priced search with resident-weight variants
     const double mf = dtype == VTI_H2 ? 2.0 : dtype == VTI_F32 ? 8.0 : 1.0;      // matrix-pipe cycles per (n-tile, m-tile, tap) in units of 16
     static const bool no_wstat = getenv("VTI_NO_PK_WSTAT") && getenv("VTI_NO_PK_WSTAT")[0] == '1';
     double best = 1e30;
@@ -190,7 +191,8 @@ static bool choose_pk2_cfg(int dtype, const ConvRow& r, int max_batch, ConvCfg& 
     if (no && no[0] == '1') return false;
     if (!(r.k == 3 && r.s == 2 && r.kind == 0) || r.w_out < 20) return false;
     const int esize = dtype == VTI_F16 ? 2 : 4;
-    const bool wide = dtype != VTI_F16;
+    static const bool wide16 = getenv("VTI_PK_WIDE16") && getenv("VTI_PK_WIDE16")[0] == '1';
+    const bool wide = dtype != VTI_F16 || wide16;
     const double mf = dtype == VTI_H2 ? 2.0 : dtype == VTI_F32 ? 8.0 : 1.0;
     static const bool no_wstat = getenv("VTI_NO_PK_WSTAT") && getenv("VTI_NO_PK_WSTAT")[0] == '1';
     double best = 1e30;
@@ -751,6 +753,11 @@ std::string Plan::build(const vti_desc& d) {
             op.cfg = ConvCfg();
             op.cfg.TH = 4; op.cfg.TW = 20; op.cfg.WN = 4; op.cfg.NREP = r.c2 / 16;
             op.cfg.nchunks = (ru.c1 + KC - 1) / KC; op.cfg.gemm_n = 4 * r.c2; op.cfg.ntiles_n = 4 * (r.c2 / 16);
+            // VTI_FOLD512=1 (4-byte storage): 8 x 20 tiles with 8-wave workgroups, two pixel groups sharing every staged weight chunk (conv.hip).
+            // Measured: no change (272 vs 273 us on the h2 engine) -- the 1.3 GB of weight staging per launch is not what bounds the kernel --
+            // so the 4-wave form (two workgroups per CU) stays the default.
+            const char* f8 = getenv("VTI_FOLD512");
+            if (d.dtype != VTI_F16 && f8 && f8[0] == '1' && ru.h_in >= 8) { op.cfg.TH = 8; op.cfg.threads = 512; }
             op.cfg.lds = convfold_lds_bytes(op.cfg.TH, op.cfg.TW);
             // persistent schedule (weights stay in LDS): fp16 only (the fp32 engine's 4 chunks of 64 KB do not fit), tensors < 2 GiB
             const char* npf = getenv("VTI_NO_PK_FOLD");

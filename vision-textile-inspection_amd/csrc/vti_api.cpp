@@ -412,7 +412,7 @@ static int32_t forward_impl(vti_ctx* c, const uint8_t* input, int32_t B, int32_t
                 memset(&q, 0, sizeof q);
                 q.in = buf_ptr(c, op.in.buf, input, proto); q.B = B; q.Hin = ru.h_in; q.Win = ru.w_in; q.Hout = ru.h_in; q.Wout = ru.w_in;
                 q.Cin = ru.c1; q.in_ld = ib.C; q.in_coff = op.in.coff; q.Cout = g.gemm_n; q.act = 1; q.fold = 1; q.pk_lin = pk_linear_map();
-                q.TH = g.TH; q.TW = g.TW; q.tiles_y = (q.Hout + g.TH - 1) / g.TH; q.tiles_x = (q.Wout + g.TW - 1) / g.TW; q.WN = 4;
+                q.TH = g.TH; q.TW = g.TW; q.tiles_y = (q.Hout + g.TH - 1) / g.TH; q.tiles_x = (q.Wout + g.TW - 1) / g.TW; q.WN = 4; q.nt = g.threads;
                 q.nchunks = g.nchunks; q.ntiles_n = g.ntiles_n;
                 q.pw_magic = (unsigned)((0x100000000ull + (unsigned)(g.TW + 2) - 1) / (unsigned)(g.TW + 2));
                 q.tw_magic = (unsigned)((0x100000000ull + (unsigned)g.TW - 1) / (unsigned)g.TW);
