@@ -374,9 +374,14 @@ def main():
     B, H, W, nc = args.batch, 640, 640, 80
     eng = vti_amd.Engine("n", nc, H=H, W=W, max_batch=B, dtype=args.dtype)
     gen = torch.Generator(device=dev)
-    gen.manual_seed(1234 + rank)
+    gen.manual_seed(1234)
     frames = torch.randint(0, 256, (B, H, W, 3), dtype=torch.uint8, device=dev, generator=gen)
+    # the class prior is calibrated on the SAME seeded frames on every rank (deterministic kernels: identical bias, i.e. the weights
+    # really are replicas); ranks > 0 then draw their own frames
     blob, bias = calibrated_weights(vti_amd, eng, frames, CONF, target=60)
+    if rank > 0:
+        gen.manual_seed(1234 + rank)
+        frames = torch.randint(0, 256, (B, H, W, 3), dtype=torch.uint8, device=dev, generator=gen)
     cap = B * SLOTS_PER_FRAME
     outs = [eng.alloc_outputs(B, MAX_DET, cap, "bits", dev) for _ in range(2)]
     for o in outs:                           # a gather that runs before this buffer's first post-processing must see "no detections"
