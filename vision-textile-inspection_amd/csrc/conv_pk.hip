@@ -957,7 +957,11 @@ bool bneck_pk_fits(int TH, int NREP) {
 // ConvParams: in_coff = y0's offset, w0 = [Wa tile 0, Wa tile 1, Wb tile 0, Wb tile 1] fragments, bias0 = the 1x1's bias, out2 = its output.
 template <typename T, int NREP, bool TAIL = false>
 __global__ __launch_bounds__(512) void bneck_pk(const ConvParams p) {
-    static_assert(!TAIL || (sizeof(T) == 2 && NREP == 1), "tail: fp16, 16 channels");
+    static_assert(!TAIL || ((sizeof(T) == 2 || Tr<T>::H2) && NREP == 1), "tail: fp16 / h2, 16 channels");
+    // h2 tail: a 64-byte slot holds 16 channels, so the patch carries y1 only (no in_coff shift); y0 of the tile's own pixels is read
+    // straight from global memory as an MFMA operand (five 16-byte loads per lane and tile, issued at the top of the tile), and the 1x1
+    // is three steps per (m-tile, n-tile): Wa0 . y0 + Wa1 . y1(patch) + Wb . y2(registers), one common weight scale (alpha0).
+    constexpr bool TAILH2 = TAIL && Tr<T>::H2;
     using vec = typename Tr<T>::vec;
     constexpr int VEC = Tr<T>::VEC, ES = (int)sizeof(T);
     constexpr int TAPS = 9, R1W = PK_TW + 2;
@@ -1006,7 +1010,7 @@ __global__ __launch_bounds__(512) void bneck_pk(const ConvParams p) {
         const int lw = wave - nwm, nld = nwm;
         const int ndma = PH * PK_PWP / 16;
         const int q = (lane & 3) ^ (((lane >> 4) & 1) << 1);
-        const bool qok = q * VEC < (TAIL ? 2 * p.Cin : p.Cin);   // one chunk: channel pieces beyond Cin are written as zeros (tail: y0 | y1)
+        const bool qok = q * VEC < ((TAIL && !TAILH2) ? 2 * p.Cin : p.Cin);   // one chunk: channel pieces beyond Cin are written as zeros (fp16 tail: y0 | y1)
         int dyx[PK_MAXD];
 #pragma unroll
         for (int u = 0; u < PK_MAXD; ++u) {
@@ -1100,13 +1104,23 @@ __global__ __launch_bounds__(512) void bneck_pk(const ConvParams p) {
             xa2[m][dx] = timg_off + ((s * 64 + g * 16) ^ ((s & 4) << 3));
         }
         const int sr = (ry[m] + 2) * PK_PWP + px + 2;       // the pixel itself in the input patch (shortcut)
-        const int piece = ((sizeof(T) == 2 && NREP == 1) ? (g >> 1) : g) + (TAIL ? 2 : 0);      // tail: y1 is the slot's upper half
+        const int piece = ((sizeof(T) == 2 && NREP == 1) ? (g >> 1) : g) + ((TAIL && !TAILH2) ? 2 : 0);      // fp16 tail: y1 is the slot's upper half
         ra[m] = ((sr * 64 + piece * 16) ^ ((sr & 4) << 3)) + ((sizeof(T) == 2 && NREP == 1) ? (g & 1) * 8 : 0);
         xc[m] = (sr * 64 + g * 16) ^ ((sr & 4) << 3);       // tail: the pixel's [y0 | y1] as an MFMA operand (k-group g = piece g)
     }
     [[maybe_unused]] vec wA[2], wB[2];
     [[maybe_unused]] f32x4 b3r[2];
-    if constexpr (TAIL) {
+    [[maybe_unused]] u32x4 th[TAILH2 ? 6 : 1], tl[TAILH2 ? 6 : 1];   // h2 tail: prepared operands of [Wa0 n0, Wa0 n1, Wa1 n0, Wa1 n1, Wb n0, Wb n1], kernel-invariant
+    if constexpr (TAILH2) {
+#pragma unroll
+        for (int f = 0; f < 6; ++f) {
+            const u32x4 raw = ((const u32x4*)p.w0)[f * 64 + lane];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { th[f][i] = __builtin_amdgcn_perm(raw[i], raw[i], 0x01000100u); tl[f][i] = raw[i] >> 16; }
+        }
+#pragma unroll
+        for (int n = 0; n < 2; ++n) b3r[n] = *(const f32x4*)(p.bias0 + g * 8 + 4 * n);
+    } else if constexpr (TAIL) {
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
             wA[n] = ((const vec*)p.w0)[n * 64 + lane];
@@ -1114,6 +1128,7 @@ __global__ __launch_bounds__(512) void bneck_pk(const ConvParams p) {
             b3r[n] = *(const f32x4*)(p.bias0 + g * 8 + 4 * n);      // permuted rows (NREP2 = 2): lane group g owns channels 8 g .. 8 g + 7
         }
     }
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, TAILH2 ? (int)p.in_bytes : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsO2 = __builtin_amdgcn_make_buffer_rsrc(p.out2, 0, TAIL ? (int)p.out2_bytes : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)p.out_bytes, 0x00020000);
     const int crun = g * 4 * NREP;
@@ -1130,6 +1145,16 @@ __global__ __launch_bounds__(512) void bneck_pk(const ConvParams p) {
         int b, oy0, ox0;
         tile_coords(t, b, oy0, ox0);
         const char* sx = smem + (step % D) * stage_bytes;
+        [[maybe_unused]] u32x4 y0r[TAILH2 ? MREP : 1];
+        if constexpr (TAILH2) {                             // y0 of this wave's pixels: consumed in the tail, a whole tile of MFMAs later
+#pragma unroll
+            for (int m = 0; m < MREP; ++m) {
+                const int gy = oy0 + ry[m], gx = ox0 + rx[m];
+                const bool pv = gy < p.Hout && gx < p.Wout;
+                const int opix = (b * p.Hout + gy) * p.Wout + gx;
+                y0r[m] = buf_load16<u32x4>(rsY, pv ? (unsigned)((opix * p.in_ld + p.in_coff - p.Cin + g * 4) * ES) : OOB, 0u);
+            }
+        }
         if (step == 2) VTI_STAMP(1);
         __builtin_amdgcn_s_barrier();                       // A
         asm volatile("" ::: "memory");
@@ -1267,7 +1292,26 @@ __global__ __launch_bounds__(512) void bneck_pk(const ConvParams p) {
                         v[0] += unpack4<T>(*(const u32x4*)(sx + ra[m]));
                     }
                 }
-                if constexpr (TAIL) {
+                if constexpr (TAILH2) {
+                    const u32x4 xB = pack4<T>(v[0]);                       // y2 as it would have been stored
+                    const u32x4 xA1 = *(const u32x4*)(sx + xc[m]);        // y1: this pixel's slot of the input patch
+                    const half8 x0 = __builtin_bit_cast(half8, y0r[m]), x1 = __builtin_bit_cast(half8, xA1), x2 = __builtin_bit_cast(half8, xB);
+                    f32x4 a3[2];
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) {
+                        f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        a = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, th[n]), x0, a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, tl[n]), x0, a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, th[2 + n]), x1, a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, tl[2 + n]), x1, a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, th[4 + n]), x2, a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, tl[4 + n]), x2, a, 0, 0, 0);
+                        a3[n] = silu4<FAST>(acc_bias<T>(a, b3r[n], p.alpha0));
+                    }
+                    const unsigned ob2 = (unsigned)((opix * p.out2_ld + p.out2_coff + g * 8) * ES);
+                    __builtin_amdgcn_raw_buffer_store_b128(pack4<T>(a3[0]), rsO2, pv ? ob2 : OOB, 0u, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(pack4<T>(a3[1]), rsO2, pv ? ob2 + 16 : OOB, 0u, 0);
+                } else if constexpr (TAIL) {
                     // y2 of this pixel (rounded to T as it would have been stored) is the K operand of the second tail step:
                     // elements 0..3 = channels 4 g .. 4 g + 3 (pack_conv_stage2's K order for a one-tile producer), 4..7 = 0
                     vec xB;
@@ -1330,9 +1374,11 @@ hipError_t launch_bneck_pk(int dtype, int nrep, const ConvParams& p, size_t lds_
     if (p.Hin != p.Hout || p.Win != p.Wout || p.pk_wgs < 1 || (p.pk_xcd && p.pk_wgs % 8)) return hipErrorInvalidValue;
     if ((size_t)p.in_bytes >= 0x80000000u || (size_t)p.out_bytes >= 0x80000000u) return hipErrorInvalidValue;
     const int tail = p.w0 != nullptr;                       // the C2f's closing 1x1 in the same kernel (in_coff is then y0's offset)
-    if (tail && (dtype != VTI_F16 || nrep != 1 || !p.out2 || !p.bias0 || p.Cout2 != 32 || ((p.out2_ld | p.out2_coff) & 7) || (p.in_coff & 7)))
+    if (tail && ((dtype != VTI_F16 && dtype != VTI_H2) || nrep != 1 || !p.out2 || !p.bias0 || p.Cout2 != 32 || ((p.out2_ld | p.out2_coff) & 7) || (p.in_coff & 7)))
         return hipErrorInvalidValue;
-    if (p.has_res && (p.res != p.in || p.res_ld != p.in_ld || p.res_coff != p.in_coff + (tail ? p.Cin : 0))) return hipErrorInvalidValue;   // shortcut = the input
+    if (tail && dtype == VTI_H2 && p.in_coff < p.Cin) return hipErrorInvalidValue;      // h2: in_coff is y1's offset, y0 sits Cin channels below it
+    // shortcut = the input (fp16 tail: in_coff was moved down to y0, the shortcut y1 sits Cin above it)
+    if (p.has_res && (p.res != p.in || p.res_ld != p.in_ld || p.res_coff != p.in_coff + ((tail && dtype == VTI_F16) ? p.Cin : 0))) return hipErrorInvalidValue;
     if ((p.out_ld | p.out_coff) & (dtype == VTI_F16 ? 7 : 3)) return hipErrorInvalidValue;                              // 16-byte stores
     if (p.pk_depth < 2 || p.pk_depth > 4 || lds_bytes < bneck_pk_lds_bytes(p.TH, nrep, p.pk_depth) || lds_bytes > 160 * 1024) return hipErrorInvalidValue;
     if (p.pk_tiles == 0) return hipSuccess;
@@ -1343,6 +1389,7 @@ hipError_t launch_bneck_pk(int dtype, int nrep, const ConvParams& p, size_t lds_
         if (nrep == 1) return launch_bneck_one<half_t, 1>(p, grid, threads, lds_bytes, st);
         if (nrep == 2) return launch_bneck_one<half_t, 2>(p, grid, threads, lds_bytes, st);
     } else if (nrep == 1) {
+        if (dtype == VTI_H2 && tail) return launch_bneck_one<h2_t, 1, true>(p, grid, threads, lds_bytes, st);
         if (dtype == VTI_H2) return launch_bneck_one<h2_t, 1>(p, grid, threads, lds_bytes, st);
         return launch_bneck_one<float, 1>(p, grid, threads, lds_bytes, st);
     }

@@ -609,7 +609,7 @@ std::string Plan::build(const vti_desc& d) {
             // ... and, for an n = 1 C2f with c = 16 (fp16: [y0 | y1] is exactly one 64-byte slot), its closing 1x1 over [y0 | y1 | y2]:
             // the tail of bneck_pk.  Y = [y0 | y1 | y2] in one buffer; the pair reads y1 (shortcut too) and would write y2.
             const char* nt = getenv("VTI_NO_BNECK_TAIL");
-            if (!(nt && nt[0] == '1') && d.dtype == VTI_F16 && ra.c1 == 16 && i + 1 < ops.size()) {
+            if (!(nt && nt[0] == '1') && (d.dtype == VTI_F16 || d.dtype == VTI_H2) && ra.c1 == 16 && i + 1 < ops.size()) {
                 Op& a2 = ops[i];
                 const Op& c3 = ops[i + 1];
                 const int Y = a2.in.buf, c = ra.c1;
@@ -804,7 +804,7 @@ std::string Plan::build(const vti_desc& d) {
             const ConvRow& rt = convs[op.tail];
             macs += rt.macs(); fused_params += rt.fused_params();
             op.cfg.wpk_off3 = woff; op.cfg.bias_off3 = boff;
-            woff += 4 * 1024; boff += 32;
+            woff += (d.dtype == VTI_F16 ? 4 : 6) * 1024; boff += 32;      // h2: Wa is two 16-channel chunks
         }
         if (op.fused_l1 >= 0) {
             const ConvRow& r1 = convs[op.fused_l1];

@@ -473,7 +473,8 @@ static int32_t forward_impl(vti_ctx* c, const uint8_t* input, int32_t B, int32_t
                 if (p.pk != 3) return fail(c, VTI_ERR_UNSUPPORTED, "fused bottleneck needs the persistent kernel (tensor too large?)");
                 if (op.tail >= 0) {     // + the C2f's closing 1x1: the patch carries [y0 | y1] (in_coff = y0's offset), y2 is not stored
                     const Buf& o2 = P.bufs[op.out2.buf];
-                    p.in_coff -= r.c1;
+                    if (dt == VTI_F16) p.in_coff -= r.c1;          // fp16: one 64-byte slot = [y0 | y1]; h2: the patch stays y1, y0 is read directly
+                    p.alpha0 = c->alpha[op.tail];
                     p.w0 = (const char*)c->d_wpk + g.wpk_off3; p.bias0 = c->d_bias + g.bias_off3;
                     p.out2 = buf_ptr(c, op.out2.buf, input, proto); p.out2_ld = o2.C; p.out2_coff = op.out2.coff; p.Cout2 = P.convs[op.tail].c2;
                     const size_t o2b = (size_t)B * p.Hout * p.Wout * o2.C * P.esize;

@@ -343,6 +343,16 @@ std::string pack_weights(const Plan& plan, const void* blob, size_t nbytes, std:
             ConvRow rb2 = r; rb2.c1 = cb;
             ConvCfg ac; ac.nchunks = 1; ac.ntiles_n = 2; ac.NREP = 2; ac.gemm_n = r.c2;
             uint8_t* dst = wpk.data() + hc.wpk_off3;
+            if (plan.desc.dtype == VTI_H2) {
+                // h2: Wa as two 16-channel chunks [chunk][n-tile] + Wb [n-tile], laid out as the fp32 packing does and then encoded TOGETHER,
+                // so that the three partial products of the tail share one scale (alpha[i])
+                ac.nchunks = 2;
+                std::vector<float> tmp((size_t)6 * 256);            // 6 fragments of 64 lanes x 4 channels
+                pack_conv(VTI_F32, ra, false, ac, wa.data(), zb.data(), (uint8_t*)tmp.data(), sink.data());
+                pack_conv_stage2(VTI_F32, rb2, 1, wb.data(), b.data(), (uint8_t*)(tmp.data() + 4 * 256), bias.data() + hc.bias_off3, false);
+                emit_packed(VTI_H2, tmp, dst, &alpha[i]);
+                continue;
+            }
             pack_conv(plan.desc.dtype, ra, false, ac, wa.data(), zb.data(), dst, sink.data());
             pack_conv_stage2(plan.desc.dtype, rb2, 1, wb.data(), b.data(), dst + 2 * 1024, bias.data() + hc.bias_off3, false);
             continue;
@@ -374,7 +384,7 @@ std::string pack_weights(const Plan& plan, const void* blob, size_t nbytes, std:
             continue;
         }
         const Op& op = *op_of[i];
-        if (op.tail >= 0) {          // first 3x3 of a bottleneck with the fused tail: its input y1 is the UPPER half of the [y0 | y1] slot
+        if (op.tail >= 0 && plan.desc.dtype == VTI_F16) {          // first 3x3 of a bottleneck with the fused tail: its input y1 is the UPPER half of the [y0 | y1] slot
             pack_conv(plan.desc.dtype, r, false, op.cfg, w.data(), b.data(), wpk.data() + op.cfg.wpk_off, bias.data() + op.cfg.bias_off, r.c1);
             continue;
         }
