@@ -246,9 +246,10 @@ bool convfold_supported(int c_in, int c_mid, int c_out, int ntiles2) {
     return c_in == c_mid && c_mid % 16 == 0 && c_out == 64 && c_in % 16 == 0 && c_in <= 64 && (ntiles2 == 1 || ntiles2 == 2 || ntiles2 == 4);
 }
 
-// NT = 512 (4-byte storage, VTI_FOLD512=1): TWO groups of four phase waves on an 8 x 20 tile share one staged weight chunk.  The composed
-// weights are 64 KB per 16-channel chunk there -- 256 KB per tile for the h2 / fp32 engines, which cannot stay resident: 1.3 GB of L2 -> LDS
-// staging per launch with 80-pixel tiles.  160-pixel tiles halve that -- and the kernel takes the same 272 us: not its bound.  Kept selectable.
+// NT = 512 (the h2 plan's choice): TWO groups of four phase waves on an 8 x 20 tile share one staged weight chunk.  The composed weights are
+// 64 KB per 16-channel chunk there -- 256 KB per tile for the h2 / fp32 engines, which cannot stay resident: 1.3 GB of L2 -> LDS staging per
+// launch with 80-pixel tiles.  160-pixel tiles halve that; alone the kernel takes the same 272 us (staging is not its bound), beside the
+// other branches of the multi-stream forward it costs them less (plan.cpp).
 template <typename T, int NREP2, int NT = 256>
 __global__ __launch_bounds__(NT, NT == 512 ? 1 : 2) void convfold_kernel(const ConvParams p) {
     using vec = typename Tr<T>::vec;

@@ -460,7 +460,9 @@ std::string Plan::build(const vti_desc& d) {
     const int strides[3] = {8, 16, 32};
     num_anchors = 0;
     // lanes: level 0 is one lane (its kernels fill the chip); the small level-1/2 towers get a lane each
-    const int tower_lane[3][3] = {{2, 2, 2}, {3, 4, 5}, {6, 7, 0}};
+    // VTI_P3_LANES=1 (A/B aid): the three P3 towers on three lanes instead of one
+    static const bool p3l = getenv("VTI_P3_LANES") && getenv("VTI_P3_LANES")[0] == '1';
+    const int tower_lane[3][3] = {{2, p3l ? 8 : 2, p3l ? 9 : 2}, {3, 4, 5}, {6, 7, 0}};
     for (int l = 0; l < 3; ++l) {
         b.cur = &g_head[l];
         const Buf fb = bufs[feat[l]];
@@ -503,6 +505,7 @@ std::string Plan::build(const vti_desc& d) {
         auto add = [&](const std::vector<Op>& g) { ops.insert(ops.end(), g.begin(), g.end()); };
         add(g_p3);
         sync(OP_FORK, 1); sync(OP_FORK, 2);
+        if (p3l) { sync(OP_FORK, 8); sync(OP_FORK, 9); }
         add(g_proto); add(g_head[0]);
         add(g_p4);
         sync(OP_FORK, 3); sync(OP_FORK, 4); sync(OP_FORK, 5);
@@ -510,7 +513,7 @@ std::string Plan::build(const vti_desc& d) {
         add(g_p5);
         sync(OP_FORK, 6); sync(OP_FORK, 7);
         add(g_head[2]);
-        for (int l = 1; l <= 7; ++l) sync(OP_JOIN, l);
+        for (int l = 1; l <= (p3l ? 9 : 7); ++l) sync(OP_JOIN, l);
         Op op; op.kind = OP_DECODE; ops.push_back(op);
     }
 
@@ -753,11 +756,13 @@ std::string Plan::build(const vti_desc& d) {
             op.cfg = ConvCfg();
             op.cfg.TH = 4; op.cfg.TW = 20; op.cfg.WN = 4; op.cfg.NREP = r.c2 / 16;
             op.cfg.nchunks = (ru.c1 + KC - 1) / KC; op.cfg.gemm_n = 4 * r.c2; op.cfg.ntiles_n = 4 * (r.c2 / 16);
-            // VTI_FOLD512=1 (4-byte storage): 8 x 20 tiles with 8-wave workgroups, two pixel groups sharing every staged weight chunk (conv.hip).
-            // Measured: no change (272 vs 273 us on the h2 engine) -- the 1.3 GB of weight staging per launch is not what bounds the kernel --
-            // so the 4-wave form (two workgroups per CU) stays the default.
+            // h2: 8 x 20 tiles with 8-wave workgroups, two pixel groups sharing every staged weight chunk (conv.hip).  Alone the kernel takes the
+            // same 272 us as the 4-wave form, but inside the multi-stream forward, where the proto chain runs beside the P3 towers and the trunk,
+            // the forward is 1.4 % shorter (3.79 vs 3.84 ms, two interleaved rounds on one box: tools/fwd_ab.py).  VTI_NO_FOLD512=1 / VTI_FOLD512=1.
             const char* f8 = getenv("VTI_FOLD512");
-            if (d.dtype != VTI_F16 && f8 && f8[0] == '1' && ru.h_in >= 8) { op.cfg.TH = 8; op.cfg.threads = 512; }
+            const char* nf8 = getenv("VTI_NO_FOLD512");
+            const bool fold8 = f8 ? f8[0] == '1' : (d.dtype == VTI_H2 && !(nf8 && nf8[0] == '1'));
+            if (d.dtype != VTI_F16 && fold8 && ru.h_in >= 8) { op.cfg.TH = 8; op.cfg.threads = 512; }
             op.cfg.lds = convfold_lds_bytes(op.cfg.TH, op.cfg.TW);
             // persistent schedule (weights stay in LDS): fp16 only (the fp32 engine's 4 chunks of 64 KB do not fit), tensors < 2 GiB
             const char* npf = getenv("VTI_NO_PK_FOLD");
