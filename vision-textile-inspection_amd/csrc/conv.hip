@@ -23,6 +23,8 @@
 //    straight 1-KiB-per-fragment copy.
 //  * 256 threads = 4 waves; WN of them split N, 4/WN split M; each wave owns a 5 x NREP grid of
 //    16x16 accumulators (80 pixels x 16*NREP channels).
+#include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 
 #include "conv_dev.h"
@@ -577,7 +579,7 @@ size_t stem_l1_lds_bytes(int dtype) {
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void stem_l1_kernel(const ConvParams p) {
+__global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void stem_l1_kernel(const ConvParams p) {     // fp16: the LDS image fits twice per CU -> <= 256 registers
     using vec = typename Tr<T>::vec;
     constexpr int ES = (int)sizeof(T);
     // the patch's element type: T, except h2 -> plain fp16 holding the bytes' integer values (the stem's weights are w / 255 as hi / lo planes)
@@ -596,24 +598,67 @@ __global__ __launch_bounds__(256) void stem_l1_kernel(const ConvParams p) {
     char* sout = smem + CP_BYTES;                       // [stem pixel][16 ch] of T
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
-    int t = blockIdx.x;
-    const int tx = t % p.tiles_x; t /= p.tiles_x;
-    const int ty = t % p.tiles_y;
-    const int b = t / p.tiles_y;
-    const int oy0 = ty * SL_TH, ox0 = tx * SL_TW;       // layer-1 output tile origin
-    const int sy0 = 2 * oy0 - 1, sx0 = 2 * ox0 - 1;     // stem-map origin of the tile's stem pixels
+    // PERSISTENT: a workgroup walks tiles blockIdx.x, + gridDim.x, ... (one or two workgroups per CU: launch_stem_l1), and the u8 patch of
+    // the NEXT tile is loaded into registers at the top of phase 2, a whole tile of compute ahead of its use: the per-tile kernel
+    // spent 7.5 k of its 32 k cycles per tile (h2; stamps) waiting for exactly those loads at the top of every tile.
+    const int ntiles = p.B * p.tiles_y * p.tiles_x;
+    if ((int)blockIdx.x >= ntiles) return;
     const int Hs = (p.Hin - 1) / 2 + 1, Ws = (p.Win - 1) / 2 + 1;       // stem map (k3 s2 p1)
+    const int rowbytes = p.Win * 3;
+    auto tile_geom = [&](int tt, int& b_, int& oy0_, int& ox0_) {
+        const int tx = tt % p.tiles_x, r = tt / p.tiles_x;
+        b_ = r / p.tiles_y; oy0_ = (r % p.tiles_y) * SL_TH; ox0_ = tx * SL_TW;
+    };
+    VTI_STAMP(0);
+    // ---- phase 1: u8 -> T(v / 255) while staging.  fp16: v * (1/255) rounds to the same half as v / 255 for all 256 byte
+    // values (checked exhaustively), so no table and no division; fp32 divides (what torch's `im.float() / 255` does).
+    // wave w stages rows w, w+4, ...; a row is SL_RWD dwords = RC lane-chunks: all row arithmetic is scalar, the column test
+    // is done once per chunk, and every load of the wave is issued (branch-free) before the first one is consumed
+    constexpr int RC = (SL_RWD + 63) / 64, NR = (SL_RH + 3) / 4;
+    unsigned vv[NR][RC];
+    const bool aligned = (rowbytes & 3) == 0;
+    // straight-line code: every load is unconditional (clamped address) and NOTHING consumes a result here -- a select or a branch
+    // per load makes the compiler wait for each one (18 serialised round trips: 20 k cycles per workgroup, measured).  The masks
+    // are re-derived where the values are consumed (top of the tile's iteration).
+    auto issue_raw = [&](int tt) {
+        int b_, oy0_, ox0_;
+        tile_geom(tt, b_, oy0_, ox0_);
+        const int iy0_ = 2 * (2 * oy0_ - 1) - 1, a0_ = ((2 * (2 * ox0_ - 1) - 1) * 3) & ~3;
+        const uint8_t* inb_ = (const uint8_t*)p.in + (size_t)b_ * p.Hin * p.Win * 3;
+#pragma unroll
+        for (int it = 0; it < NR; ++it) {
+            const int ry = wave + 4 * it;
+            const int y = iy0_ + ry;
+            const bool row_ok = ry < SL_RH && (unsigned)y < (unsigned)p.Hin;
+#pragma unroll
+            for (int ch = 0; ch < RC; ++ch) {
+                const int rd = lane + 64 * ch;
+                const int gx = a0_ + 4 * rd;
+                const bool ok = row_ok && rd < SL_RWD && gx >= 0 && gx < rowbytes;
+                vv[it][ch] = *(const unsigned*)(inb_ + (ok ? (size_t)y * rowbytes + gx : (size_t)0));
+            }
+        }
+    };
+    if (aligned) issue_raw((int)blockIdx.x);
+    for (int t = (int)blockIdx.x; t < ntiles; t += (int)gridDim.x) {
+    int b, oy0, ox0;                                    // layer-1 output tile origin
+    tile_geom(t, b, oy0, ox0);
+    const int sy0 = 2 * oy0 - 1, sx0 = 2 * ox0 - 1;     // stem-map origin of the tile's stem pixels
     const int iy0 = 2 * sy0 - 1;
     const int x0b = (2 * sx0 - 1) * 3, a0 = x0b & ~3;           // x0b = 12 ox0 - 9, so x0b - a0 == 3 for every tile (phase 2 relies on it)
     const uint8_t* inb = (const uint8_t*)p.in + (size_t)b * p.Hin * p.Win * 3;
-    const int rowbytes = p.Win * 3;
-    VTI_STAMP(0);
+    // (per tile, not per workgroup: kept across the tile loop these ~190 registers push the kernel to one wave per SIMD for fp16 and into
+    // scratch for h2; re-fetched they are L2 hits whose latency hides under the patch conversion)
     // Every weight fragment of the three convs is fetched NOW (fp16: 48 + 40 + 8 registers), so that the round trips hide under the
     // patch staging: loaded where they are used, each phase opened with an exposed L2 latency (the stem phase alone spent ~6 k of
     // its 12 k cycles per workgroup waiting for its 12 fragments).
+    // the pointers are laundered through an empty asm each iteration so that the loop-invariant loads are NOT hoisted out of the tile loop
+    const void* w0p = p.w0;
+    const void* w1p = p.wpk;
+    asm volatile("" : "+s"(w0p), "+s"(w1p));
     pvec wA[4][3][NCH * NWP];
     {
-        const pvec* w0 = (const pvec*)p.w0 + (size_t)(p.swap_rb ? 1 : 0) * (4 * 3 * NCH * NWP * 64);
+        const pvec* w0 = (const pvec*)w0p + (size_t)(p.swap_rb ? 1 : 0) * (4 * 3 * NCH * NWP * 64);
 #pragma unroll
         for (int pp = 0; pp < 4; ++pp)
 #pragma unroll
@@ -625,33 +670,12 @@ __global__ __launch_bounds__(256) void stem_l1_kernel(const ConvParams p) {
 #pragma unroll
     for (int s1 = 0; s1 < NS1; ++s1)
 #pragma unroll
-        for (int n = 0; n < 2; ++n) w1all[s1][n] = ((const vec*)p.wpk)[((size_t)s1 * 2 + n) * 64 + lane];
+        for (int n = 0; n < 2; ++n) w1all[s1][n] = ((const vec*)w1p)[((size_t)s1 * 2 + n) * 64 + lane];
     const f32x4 bias0_4 = *(const f32x4*)(p.bias0 + g * 4);
     Stage2Regs<T, 2, 2> s2r;
     if (p.out2) stage2_preload<T, 2, 2>(p, lane, false, s2r);
-    // ---- phase 1: u8 -> T(v / 255) while staging.  fp16: v * (1/255) rounds to the same half as v / 255 for all 256 byte
-    // values (checked exhaustively), so no table and no division; fp32 divides (what torch's `im.float() / 255` does).
-    {   // wave w stages rows w, w+4, ...; a row is SL_RWD dwords = RC lane-chunks: all row arithmetic is scalar, the column test
-        // is done once per chunk, and every load of the wave is issued (branch-free) before the first one is consumed
-        constexpr int RC = (SL_RWD + 63) / 64, NR = (SL_RH + 3) / 4;
-        unsigned vv[NR][RC];
-        if ((rowbytes & 3) == 0) {
-            // straight-line code: every load is unconditional (clamped address) and NOTHING consumes a result inside this
-            // block -- a select or a branch per load makes the compiler wait for each one (18 serialised round trips:
-            // 20 k cycles per workgroup, measured).  The masks are re-derived after the loads.
-#pragma unroll
-            for (int it = 0; it < NR; ++it) {
-                const int ry = wave + 4 * it;
-                const int y = iy0 + ry;
-                const bool row_ok = ry < SL_RH && (unsigned)y < (unsigned)p.Hin;
-#pragma unroll
-                for (int ch = 0; ch < RC; ++ch) {
-                    const int rd = lane + 64 * ch;
-                    const int gx = a0 + 4 * rd;
-                    const bool ok = row_ok && rd < SL_RWD && gx >= 0 && gx < rowbytes;
-                    vv[it][ch] = *(const unsigned*)(inb + (ok ? (size_t)y * rowbytes + gx : (size_t)0));
-                }
-            }
+    {
+        if (aligned) {
 #pragma unroll
             for (int it = 0; it < NR; ++it) {
                 const int ry = wave + 4 * it;
@@ -719,6 +743,7 @@ __global__ __launch_bounds__(256) void stem_l1_kernel(const ConvParams p) {
     }
     __syncthreads();
     VTI_STAMP(1);
+    if (aligned && t + (int)gridDim.x < ntiles) issue_raw(t + (int)gridDim.x);      // next tile's patch: in flight under phases 2-4
     // ---- phase 2: stem as a Toeplitz GEMM -- no gathers.  Output pixel sx of a stem row reads patch elements 6 sx + 3 .. 6 sx + 11
     // of input rows 2 sy + kh (the tile's byte offset inside its first dword is always 3: 12 ox0 - 9), so the FOUR pixels 4J .. 4J+3
     // read inside the ALIGNED 32-element window [24 J, 24 J + 32) of each of the three rows.  One MFMA column = one window (16 windows
@@ -809,12 +834,21 @@ __global__ __launch_bounds__(256) void stem_l1_kernel(const ConvParams p) {
     if (p.out2) conv_stage2<T, 2, 2, false, true>(p, acc, pvalid, opy, opx, b, lane, &s2r);
     else conv_epilogue<T, 2>(p, acc, pvalid, opy, opx, b, 0, 0, lane);
     VTI_STAMP(12);
+    }       // tiles of this workgroup
 }
 
 void stem_l1_tile(int* th, int* tw) { *th = SL_TH; *tw = SL_TW; }
 
+// persistent grid: as many workgroups as fit the chip at once (one per CU; two where the LDS image fits twice: fp16)
+int stem_l1_grid(int dtype, int ntiles) {
+    const int wgpc = (int)std::min<size_t>(2, (160 * 1024) / stem_l1_lds_bytes(dtype));
+    const char* np = getenv("VTI_STEM_NOT_PERSISTENT");          // A/B aid: one workgroup per tile, as before
+    if (np && np[0] == '1') return ntiles;
+    return std::min(ntiles, 256 * std::max(1, wgpc));
+}
+
 hipError_t launch_stem_l1(int dtype, const ConvParams& p, hipStream_t st) {
-    dim3 grid((unsigned)(p.B * p.tiles_y * p.tiles_x));
+    dim3 grid((unsigned)stem_l1_grid(dtype, p.B * p.tiles_y * p.tiles_x));
     if (grid.x == 0) return hipSuccess;
     const size_t lds = stem_l1_lds_bytes(dtype);
     if (dtype == VTI_F16) {

@@ -385,7 +385,7 @@ static int32_t forward_impl(vti_ctx* c, const uint8_t* input, int32_t B, int32_t
 #ifdef VTI_STAMPS
                 if (const char* so = getenv("VTI_STAMP_OP")) {
                     if (r.name == so) {
-                        const size_t nwg = (size_t)B * q.tiles_y * q.tiles_x;
+                        const size_t nwg = (size_t)stem_l1_grid(dt, B * q.tiles_y * q.tiles_x);
                         unsigned long long* d_st = nullptr;
                         if (hipMalloc((void**)&d_st, nwg * 16 * 8) == hipSuccess) {
                             (void)hipMemset(d_st, 0, nwg * 16 * 8);

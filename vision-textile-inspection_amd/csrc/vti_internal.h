@@ -148,6 +148,7 @@ bool conv_cfg_fits(int ks, int stride, int mode, int TH, int TW, int WN, int NRE
 hipError_t launch_stem_l1(int dtype, const ConvParams& p, hipStream_t st);
 size_t stem_l1_lds_bytes(int dtype);
 void stem_l1_tile(int* th, int* tw);
+int stem_l1_grid(int dtype, int ntiles);     // workgroups of the (persistent) launch
 void pack_stem_toeplitz(int dtype, const ConvRow& r0, const float* w, const float* b, uint8_t* dst_w, float* dst_b, float* alpha = nullptr);
 size_t packed_stem_toeplitz_bytes(int dtype);
 // ConvTranspose2d(C,C,2,2) folded into the following 3x3 conv (+ its fused 1x1): four 2x2 convs on the low-resolution map
