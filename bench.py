@@ -516,6 +516,15 @@ def main():
     value = total_frames / elapsed
     flops_per_forward = 2.0 * eng.macs_per_frame * B
     achieved = flops_per_forward / (fwd_ms * 1e-3) / 1e12
+    # MACs the kernels actually issue: the ConvTranspose folded into the 3x3 behind it runs as four 2x2 convs on the low-resolution map
+    # (h_in * w_in * c1 * 4 * c2 * 4 MACs instead of the two layers' own); every other conv issues its algorithmic MACs
+    tab = eng.conv_table()
+    exec_macs = eng.macs_per_frame
+    for i, tr in enumerate(tab):
+        if tr["kind"] == 2 and tr["lds"] == 0 and i + 1 < len(tab):         # folded deconv (vti_conv_at reports it without an LDS size of its own)
+            nxt = tab[i + 1]
+            exec_macs += tr["h_in"] * tr["w_in"] * tr["c1"] * 4 * nxt["c2"] * 4 - tr["macs"] - nxt["macs"]
+    flops_executed = 2.0 * exec_macs * B
     peak = PEAKS[args.dtype]
 
     # HBM bytes per forward from the committed rocprofv3 PMC passes (tools/make_profiles.sh): only
@@ -550,6 +559,9 @@ def main():
                          "traffic_note": "HBM bytes per forward (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes, profiles/" + os.path.basename(tpath) + "); algorithmic unfused activation bytes = 91.6 MB/frame",
                          "kernel": f"vti conv family: conv3_pk / conv1_pk (persistent LDS-DMA 3x3 / 1x1) + conv_kernel (fused towers, stride 2) + stem_l1_kernel ({eng.num_launches} launches per forward incl. the SPPF pool; {len(eng.conv_table())} convs, {sum(1 for t in eng.conv_table() if t['fused'])} fused into their producer's kernel, decode fused into the box towers)",
                          "flop_per_launch": flops_per_forward, "avg_ms": round(fwd_ms, 4),
+                         "flop_executed_per_launch": flops_executed,
+                         "executed_note": "algebraic fold of proto.upsample into proto.cv2: the kernels issue this many flops for the same result; `achieved` and `frac` use the ALGORITHMIC count (SURVEY 8d), the matrix pipe's own utilisation follows from the executed one: "
+                                          + f"{flops_executed / (fwd_ms * 1e-3) / 1e12 * (4.0 if args.dtype == 'h2' else 1.0) / (F32_MFMA_PEAK_TFLOPS if args.dtype == 'fp32' else MFMA_PEAK_TFLOPS):.4f} of its peak",
                          "isolated": {"avg_ms": round(iso_ms, 4), "achieved": round(flops_per_forward / (iso_ms * 1e-3) / 1e12, 2),
                                       "frac": round(flops_per_forward / (iso_ms * 1e-3) / 1e12 / peak, 5),
                                       "note": f"the same forward alone on the chip, {n_iso} back-to-back launches after the timed region"}},
