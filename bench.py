@@ -332,6 +332,9 @@ def main():
     ap.add_argument("--dry", action="store_true", help="no GPU, no kernels: run the rank launch + per-step exchange + JSON path on CPU tensors (tests)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exchange", action="store_true", help="N>1: skip the per-step scatter/gather")
+    ap.add_argument("--rehearse-exchange", action="store_true",
+                    help="N=1 only: open a ONE-rank process group on --backend and run the per-step scatter/gather through it (the RCCL code "
+                         "path of the N>1 run -- dtypes, streams, receive buffers -- on a single-GPU box); the line is marked as a rehearsal")
     ap.add_argument("--gather-masks", action="store_true",
                     help="N>1: also ship every rank's LIVE bit-packed mask slots to the root each step (variable-length point-to-point "
                          "gather, one host read of the slot count per step); default: dets/counts/xyxy + on-device reductions only")
@@ -366,9 +369,11 @@ def main():
         sys.exit(2)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    grouped = world > 1 or args.rehearse_exchange      # a process group exists (world == 1 only under --rehearse-exchange)
+    if grouped:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group(args.backend, rank=rank, world_size=world, device_id=dev)   # "nccl" == RCCL on ROCm
 
     B, H, W, nc = args.batch, 640, 640, 80
@@ -389,8 +394,8 @@ def main():
     shards = [frames, frames.clone()]
     FABRIC_CLS = 1                          # the reference's FABRIC_CLASS_ID (config.py:70): whose union envelope the consumer reads
 
-    exchange = world > 1 and not args.no_exchange
-    exch_note = "none (single GPU)" if world == 1 else "disabled (--no-exchange)"
+    exchange = grouped and not args.no_exchange
+    exch_note = "none (single GPU)" if not grouped else "disabled (--no-exchange)"
     if exchange:                            # what the consumer needs from a frame travels, not the mask buffer
         for o in outs:
             o["stats"] = torch.empty((cap, 5), dtype=torch.int64, device=dev)
@@ -456,7 +461,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if grouped:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -480,7 +485,7 @@ def main():
             step(n_heat); n_heat += 1
         torch.cuda.synchronize()
         heated = time.perf_counter() - t_heat
-        if world > 1:                                # every rank must run the same number of (collective) steps
+        if grouped:                                  # every rank must run the same number of (collective) steps
             heated = dp.max_over_ranks(heated, dev)
         if heated >= args.preheat:
             break
@@ -494,7 +499,7 @@ def main():
         step(k, k)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if grouped:
         elapsed = dp.max_over_ranks(elapsed, dev)
 
     # the forward alone (nothing else on the chip), HIP events on the launch stream, right after the timed region
@@ -548,7 +553,8 @@ def main():
                        "pipeline": ("post-processing of batch k overlaps the network of batch k+1 on a second stream"
                                     if pipelined else "network and post-processing in series"),
                        "mask_capacity": cap, "masks_dropped": max(0, int(outs[(args.steps - 1) & 1]["offsets"][-1].item()) - cap), "parallelism": f"dp{world}", "exchange": exch_note,
-                       "ranks": world, "backend": args.backend if world > 1 else None},
+                       "ranks": world, "backend": args.backend if grouped else None,
+                       **({"rehearsal": "one-rank process group: the N>1 exchange path on a single GPU, not a scaling number"} if args.rehearse_exchange else {})},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 5), "traffic": traffic,
                          "peak_note": ("f16x2 (split-fp16): 2517 / 3 -- an algorithmic MAC costs at least three fp16 MFMA MACs (wh*xh, wh*xl, wl*xh)"
@@ -580,7 +586,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(blob, H, W, nc)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if grouped:
         torch.distributed.destroy_process_group()
 
 

@@ -48,13 +48,15 @@ __global__ __launch_bounds__(256) void mask_stats_bits_kernel(const unsigned* __
         __syncthreads();
     }
     const int wpr = W >> 5;                 // 32-bit words per mask row (W is a multiple of 32)
-    const unsigned* m = bits + (size_t)slot * H * wpr;
+    // a slot is H * W / 8 bytes, a multiple of 128 (H, W multiples of 32), and `bits` is 16-byte aligned (checked by the launcher):
+    // 16-byte loads, four of them in flight per thread before the first word is looked at (the loop was one dependent 4-byte load
+    // per trip: latency-bound at a third of what the masks' L2 / HBM residency gives)
+    const uint4* m4 = (const uint4*)(bits + (size_t)slot * H * wpr);
+    const int n4 = (H * wpr) >> 2;
     long long m00 = 0, m10 = 0, m01 = 0;
     int mn = INT_MAX, mx = -1;
-    for (int i = tid; i < H * wpr; i += 256) {
-        unsigned w = m[i];
-        if (!w) continue;
-        const int sy = i / wpr, x0 = (i - sy * wpr) << 5;
+    auto word = [&](unsigned w, int sy, int x0) {
+        if (!w) return;
         if (ident) {
             const int pc = __popc(w);
             // sum of the set bit positions: bit k of a position contributes 2^k times the population of its mask
@@ -64,7 +66,7 @@ __global__ __launch_bounds__(256) void mask_stats_bits_kernel(const unsigned* __
             mn = min(mn, x0 + __ffs(w) - 1); mx = max(mx, x0 + 31 - __clz(w));
         } else {
             const int wy = cy[sy];
-            if (!wy) continue;
+            if (!wy) return;
             long long rc = 0, rx = 0;
             while (w) {
                 const int sx = x0 + __ffs(w) - 1;
@@ -74,6 +76,27 @@ __global__ __launch_bounds__(256) void mask_stats_bits_kernel(const unsigned* __
                 mn = min(mn, xf[sx]); mx = max(mx, xl[sx]);
             }
             m00 += rc * wy; m10 += rx * wy; m01 += rc * ys[sy];
+        }
+    };
+    constexpr int U = 4;
+    for (int i0 = tid; i0 < n4; i0 += 256 * U) {
+        uint4 q[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + 256 * u;
+            q[u] = i < n4 ? m4[i] : make_uint4(0u, 0u, 0u, 0u);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (!(q[u].x | q[u].y | q[u].z | q[u].w)) continue;
+            const int i = (i0 + 256 * u) << 2;
+            int sy = i / wpr, c = i - sy * wpr;                           // word column inside the row; the four words may cross a row end
+            const unsigned ww[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                word(ww[k], sy, c << 5);
+                if (++c == wpr) { c = 0; ++sy; }
+            }
         }
     }
     for (int o = 32; o > 0; o >>= 1) {
@@ -94,7 +117,7 @@ __global__ __launch_bounds__(256) void mask_stats_bits_kernel(const unsigned* __
 hipError_t launch_mask_stats_bits(const uint8_t* bits, int n, const int* n_live, int H, int W, int H0, int W0, long long* stats,
                                   hipStream_t st) {
     if (n == 0) return hipSuccess;
-    if ((W & 31) || ((uintptr_t)bits & 3) || (size_t)(4 * W + 2 * H) * 4 > 60 * 1024) return hipErrorInvalidValue;
+    if ((W & 31) || (H & 31) || ((uintptr_t)bits & 15) || (size_t)(4 * W + 2 * H) * 4 > 60 * 1024) return hipErrorInvalidValue;      // 16-byte loads
     hipLaunchKernelGGL(mask_stats_bits_kernel, dim3(n), dim3(256), (size_t)(4 * W + 2 * H) * 4, st, (const unsigned*)bits, n_live, H, W, H0, W0, stats);
     return hipGetLastError();
 }
@@ -120,14 +143,31 @@ __global__ __launch_bounds__(256) void envelope_bits_kernel(const unsigned* __re
     const int wpr = W >> 5;
     const int s0 = offsets[b], s1 = min(offsets[b + 1], capacity);
     int env = -1;
-    for (int s = s0; s < s1; ++s) {
-        const float* d = dets + ((size_t)b * max_det + (s - s0)) * row;
-        if (cls >= 0 && (int)d[5] != cls) continue;
-        int ya = (int)floorf(d[1] - 8.f), yb = (int)ceilf(d[3] + 8.f);
-        ya = max(ya, 0); yb = min(yb, H - 1);
-        const unsigned* m = bits + (size_t)s * H * wpr + (sx >> 5);
-        for (int sy = yb - rg; sy >= ya; sy -= 4) {           // top of the search first: the first hit of a lane is its largest
-            if ((m[(size_t)sy * wpr] >> (sx & 31)) & 1u) { env = max(env, yl[sy]); if (yl[sy] >= 0) break; }
+    // the frame's instances of the wanted class, listed first (a thread per instance; the order is irrelevant to a max): the row
+    // search below then runs over those only -- walking all instances with one dependent class load each was the kernel's time
+    __shared__ int s_sel[256][3];
+    __shared__ int s_nsel;
+    for (int r0 = s0; r0 < s1; r0 += 256) {
+        __syncthreads();                                       // the previous round's list has been consumed
+        if (tid == 0) s_nsel = 0;
+        __syncthreads();
+        if (r0 + tid < s1) {
+            const float* d = dets + ((size_t)b * max_det + (r0 + tid - s0)) * row;
+            if (cls < 0 || (int)d[5] == cls) {
+                int ya = (int)floorf(d[1] - 8.f), yb = (int)ceilf(d[3] + 8.f);
+                ya = max(ya, 0); yb = min(yb, H - 1);
+                const int pos = atomicAdd(&s_nsel, 1);
+                s_sel[pos][0] = r0 + tid; s_sel[pos][1] = ya; s_sel[pos][2] = yb;
+            }
+        }
+        __syncthreads();
+        const int nsel = s_nsel;
+        for (int j = 0; j < nsel; ++j) {
+            const int s = s_sel[j][0], ya = s_sel[j][1], yb = s_sel[j][2];
+            const unsigned* m = bits + (size_t)s * H * wpr + (sx >> 5);
+            for (int sy = yb - rg; sy >= ya; sy -= 4) {           // top of the search first: the first hit of a lane is its largest
+                if ((m[(size_t)sy * wpr] >> (sx & 31)) & 1u) { env = max(env, yl[sy]); if (yl[sy] >= 0) break; }
+            }
         }
     }
     red[rg][tid & 63] = env;
