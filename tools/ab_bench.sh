@@ -8,7 +8,7 @@ for round in 1 2; do
     python - "$arm" <<'PY'
 import json, sys
 d = json.load(open("/tmp/ab.json"))
-print(f"{sys.argv[1]:28s} fwd {d['roofline']['avg_ms']:.4f} ms  iso {d['roofline']['isolated']['avg_ms']:.4f}  step {d['ms_per_step']:.4f}  fps {d['value']:.0f}")
+print(f"{sys.argv[1]:28s} fwd {d['roofline']['avg_ms']:.4f} ms  iso {d['roofline']['isolated']['avg_ms']:.4f}  step {d['ms_per_step']:.4f}  post {d['stage_ms']['nms+masks+scale_boxes']:.4f}  fps {d['value']:.0f}")
 PY
   done
 done
