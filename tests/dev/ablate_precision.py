@@ -3,7 +3,7 @@
 whole predict pipeline to meet the north-star gate (mask IoU >= 0.999 per instance, |d box| < 1e-3 normalised, same kept
 set) against the fp32 oracle?  Uses the oracle's rounding hook (oracle/model.py: q()) with a per-layer policy.
 
-    python tools/ablate_precision.py [--frames 8] [--out profiles/r03_precision_ablation.txt]
+    python tests/dev/ablate_precision.py [--frames 8] [--out profiles/r03_precision_ablation.txt]
 
 Policies round (a) the stored output of a conv and (b) its weights.  "h2" is the split-fp16 pair the h2 engine stores:
 v*S = hi + lo with hi = fp16(v*S), lo = fp16(v*S - hi) (22-23 significant bits).  "mN" keeps N mantissa bits.
@@ -15,7 +15,7 @@ import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402

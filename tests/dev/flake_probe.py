@@ -2,12 +2,12 @@
 """Diagnostic (GPU): the body of tests/test_gpu_predict.py::test_drop_empty_masks_flag_and_output_reuse in a loop inside ONE
 process, reporting WHICH comparison differs when one does (the test failed once in a combined run and passed alone).
 
-    python tools/flake_probe.py [iterations]
+    python tests/dev/flake_probe.py [iterations]
 """
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 

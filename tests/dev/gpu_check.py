@@ -1,7 +1,7 @@
 """Developer script (GPU box): layer-by-layer parity of the HIP forward vs the CPU oracle, then a
 rough timing.  Not part of the product; the judged checks live in tests/ and bench.py."""
 import sys, time, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 import vti_amd

@@ -1,6 +1,6 @@
 """First look at the h2 engine on the GPU: per-layer error vs the fp32 oracle, forward time, parity gate."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import vti_amd
 from oracle.model import OracleModel

@@ -3,13 +3,13 @@
 pre-filled with a poison byte, N times, compared with the first run -- dets rows below the count, counts, offsets, xyxy, the live
 mask slots and m00.  A post-processing kernel that reads memory nobody wrote (or races) shows up as a mismatch.
 
-    python tools/post_poison.py [--dtype h2] [--batch 2] [--runs 40] [--target 300]
+    python tests/dev/post_poison.py [--dtype h2] [--batch 2] [--runs 40] [--target 300]
 """
 import argparse
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
