@@ -4,7 +4,7 @@
 arms=("A=default" "$@")
 for round in 1 2; do
   for arm in "${arms[@]}"; do
-    env $arm python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-fp32-line --no-fp16-line --no-host-fed --parity-frames 0 --preheat 0.5 > /tmp/ab.json 2>/dev/null
+    env $arm python bench.py --dtype ${DT:-h2} --steps 30 --warmup 5 --no-cpu-baseline --no-fp32-line --no-fp16-line --no-host-fed --parity-frames 0 --preheat 0.5 > /tmp/ab.json 2>/dev/null
     python - "$arm" <<'PY'
 import json, sys
 d = json.load(open("/tmp/ab.json"))

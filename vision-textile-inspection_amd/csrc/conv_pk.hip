@@ -109,6 +109,19 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 template <int N> struct WaitVm { static __device__ __forceinline__ void go(int n) { if (n >= N) wait_vm<N>(); else WaitVm<N - 1>::go(n); } };
 template <> struct WaitVm<0> { static __device__ __forceinline__ void go(int) { wait_vm<0>(); } };
 
+// De-phase the two halves of a persistent 3x3 launch: the compute waves of the upper half of every XCD's workgroups (blockIdx.x >> 3
+// in the upper half of its range) start `units` x 1024 cycles late (~10 k cycles: most of a tile of the small-channel layers), the
+// loader waves at once.  Measured on the whole forward (bs 64, h2), A/B on one box at a time: -2.6 ... -4.2 % on five boxes whose
+// default forward took 3.70-3.86 ms, +-0.3 % on one that took 3.57 ms; 8-14 units alike, 20 half the gain, 28+ a loss; four groups or
+// odd/even workgroups instead of halves: no better / a third of it; the same delay in bneck_pk and conv1_pk: nothing.  The per-kernel
+// times of a single-stream run do not move -- what moves is the chip: all CUs entering their MFMA phases together is the worst case
+// for the power the clock is regulated on (MI355X_MICROARCH.md, DVFS give-back), and the boxes that gain are the ones that clock
+// lower to begin with.  Only launches that fill the chip are staggered (vti_api.cpp: fill_conv_params); VTI_PK_STAGGER=0 turns it off.
+__device__ __forceinline__ void pk_stagger_wait(int units) {
+    if (units > 0 && (int)(blockIdx.x >> 3) * 2 >= (int)(gridDim.x >> 3))
+        for (int i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(16);
+}
+
 // FOLD: the ConvTranspose2d(2,2) -> 3x3 fold of conv.hip's convfold_kernel on this schedule: TH = 4, WN = 4 -- compute wave wn is
 // output phase (py, px) = (wn >> 1, wn & 1) and runs the 2x2 window that starts at patch (py, px) over the SAME 4 x 20 low-resolution
 // pixels as its three siblings (4 taps instead of 9; both K chunks of the 128 KB of composed weights stay in LDS for the whole
@@ -288,6 +301,7 @@ __global__ __launch_bounds__(512) void conv3_pk(const ConvParams p) {
     Stage2Regs<T, NREP, NREP2 ? NREP2 : 1> s2r;
     if constexpr (FOLD) stage2_preload<T, NREP, NREP2>(p, lane, true, s2r);
     VTI_STAMP(0);
+    pk_stagger_wait(p.pk_stagger);
     while (true) {
         f32x4 acc[MREP][NREP];
 #pragma unroll

@@ -240,6 +240,13 @@ static void* buf_ptr(vti_ctx* c, int buf, const void* input, void* proto) {
     return c->ws + c->plan.bufs[buf].off;
 }
 
+// Delay units (x 1024 cycles) of the staggered persistent 3x3 launches.  h2 only by default: -2.6 ... -4.2 % per forward on five of
+// seven boxes (A/B on one box at a time), +0.8 % on the two fastest; fp16: +0.2 ... +1 % on a fast box, fp32: nothing.  VTI_PK_STAGGER=n overrides.
+static int stagger_units(int dtype) {
+    static const int v = getenv("VTI_PK_STAGGER") ? std::max(0, std::min(255, atoi(getenv("VTI_PK_STAGGER")))) : -1;
+    return v >= 0 ? v : (dtype == VTI_H2 ? 10 : 0);
+}
+
 static int pk_linear_map() {       // A/B aid: VTI_PK_LINEAR_MAP=1 restores the linear pixel -> column-tile map of the persistent 3x3 kernels
     static const int v = getenv("VTI_PK_LINEAR_MAP") && getenv("VTI_PK_LINEAR_MAP")[0] == '1';
     return v;
@@ -304,6 +311,9 @@ static void fill_conv_params(int conv_elem_size, ConvParams& p, const ConvRow& r
         p.pk_xcd = G >= 8 ? 1 : 0;
         if (p.pk_xcd) G &= ~7;
         p.pk_wgs = G;
+        // launches that fill the chip start the upper half of their workgroups late (conv_pk.hip: pk_stagger_wait): eligibility here,
+        // the caller scales it by stagger_units(dtype)
+        p.pk_stagger = ((g.pk == 1 || g.pk == 4) && p.pk_tiles >= std::max(1, 256 * g.pk_wgpc / gy) && G >= 16) ? 1 : 0;
     }
 }
 
@@ -446,6 +456,7 @@ static int32_t forward_impl(vti_ctx* c, const uint8_t* input, int32_t B, int32_t
                              op.has_res ? P.bufs[op.res.buf].C : 0, op.res.coff,
                              (const char*)c->d_wpk + g.wpk_off, c->d_bias + g.bias_off, op.out_f32, swap_rb);
             p.alpha = c->alpha[op.conv]; p.alpha0 = 1.f;
+            p.pk_stagger *= stagger_units(dt);
             p.alpha2 = op.fused >= 0 ? c->alpha[op.fused] : op.pair >= 0 ? c->alpha[op.pair] : 1.f;
             if (op.fused >= 0) {
                 const Buf& o2 = P.bufs[op.out2.buf];
@@ -754,6 +765,7 @@ int32_t vti_debug_conv2d(int32_t dtype, const void* dev_in, int32_t B, int32_t H
         fill_conv_params(dtype == VTI_F16 ? 2 : 4, p, r, g, B, dev_in, in_ld, in_coff, dev_out, out_ld, out_coff, dev_res, res_ld, res_coff, d_w, d_b,
                          out_f32 != 0, swap_rb);
         p.alpha = alpha; p.alpha2 = p.alpha0 = 1.f;
+        p.pk_stagger *= stagger_units(dtype);
         const int ks = kind == 2 ? 1 : k, ss = kind == 2 ? 1 : s;
 #ifdef VTI_STAMPS
         {   // diagnostic build: one stamped launch, medians of the phase intervals to stderr

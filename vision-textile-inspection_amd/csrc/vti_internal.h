@@ -128,6 +128,7 @@ struct ConvParams {
     // persistent kernel (conv_pk.hip): tile count, workgroups along x, XCD-contiguous tile ranges, tensor sizes
     int pk, pk_tiles, pk_wgs, pk_xcd, pk_depth, pk_wstat, pk_lin /* 1: linear pixel -> column-tile map (A/B aid) */;
     int pk_cps;                          // conv1_pk: K chunks per step (1 fp16, 2 for 4-byte storage)
+    int pk_stagger;                      // conv3_pk: the upper half of every XCD's workgroups starts its compute waves this many x 1024 cycles late (0: off)
     unsigned in_bytes, out_bytes, res_bytes, out2_bytes;
     // conv1_pk: channels [0, up_C) come from in2 [B, Hout/2, Wout/2, in2_ld] at (y >> 1, x >> 1): the neck's Upsample + Concat folded into the loads
     const void* in2; int in2_ld, in2_coff, up_C; unsigned in2_bytes;
