@@ -111,13 +111,11 @@ template <> struct WaitVm<0> { static __device__ __forceinline__ void go(int) { 
 
 // De-phase the two halves of a persistent 3x3 launch: the compute waves of the upper half of every XCD's workgroups (blockIdx.x >> 3
 // in the upper half of its range) start `units` x 1024 cycles late (~10 k cycles: most of a tile of the small-channel layers), the
-// loader waves at once.  Measured on the whole forward (bs 64, h2), A/B on one box at a time: -2.6 ... -4.2 % on five boxes whose
-// default forward took 3.70-3.86 ms, +-0.3 % on one that took 3.57 ms; 8-14 units alike, 20 half the gain, 28+ a loss; four groups or
-// odd/even workgroups instead of halves: no better / a third of it; a ramp over the eight XCDs instead: the same; the same delay in
-// bneck_pk, conv1_pk and the stem kernel: nothing.  The per-kernel
-// times of a single-stream run do not move -- what moves is the chip: all CUs entering their MFMA phases together is the worst case
-// for the power the clock is regulated on (MI355X_MICROARCH.md, DVFS give-back), and the boxes that gain are the ones that clock
-// lower to begin with.  Only launches that fill the chip are staggered (vti_api.cpp: fill_conv_params); VTI_PK_STAGGER=0 turns it off.
+// loader waves at once.  Measured on the whole forward (bs 64, h2), A/B on one box at a time: -2.4 ... -4.7 % on the eight boxes whose
+// default forward took 3.70-3.89 ms, +0.6 ... 0.8 % on the three that took 3.51-3.57 ms.  No single kernel gets faster (a hot loop of one
+// layer is 0-4 % slower staggered, and subsets of the launches give nothing): the chip does once the forward's MFMA-dense launches stop
+// moving all CUs in lockstep -- DESIGN.md section 7 has the experiments.  Only launches that fill the chip are staggered
+// (vti_api.cpp: fill_conv_params, stagger_units); VTI_PK_STAGGER=0 turns it off.
 __device__ __forceinline__ void pk_stagger_wait(int units) {
     if (units > 0 && (int)(blockIdx.x >> 3) * 2 >= (int)(gridDim.x >> 3))
         for (int i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(16);
